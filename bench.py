@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""bench.py -- dofs/sec of the stiffness-operator apply on a P4 hex box mesh.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it
+is launched under torch.distributed.run, one rank per GPU (RCCL).  W untimed
+warm-up steps, then EXACTLY K timed steps bracketed by barrier +
+torch.cuda.synchronize(); MAX over ranks; rank 0 prints ONE JSON line.
+
+A "step" is one pass of the hot path over the resident synthetic mesh:
+    y += K x   (stiffness apply, the metric's operator)   then
+    kv = y / m (lumped-mass-inverse apply, BASELINE.json configs[1])
+N = 1 : BASELINE.json configs[1]: P4, 54^3 cells, 10 218 313 dofs.
+N > 1 : weak scaling, 54^3 cells per GPU on a Cartesian partition of the box,
+        forward ghost update of x before and reverse (add) update of y after the
+        local apply (common/LinearGLL.hpp:164-176) through VectorUpdater.
+value = global owned dofs / (seconds per step)  -- the reference's definition
+        index_map->size_local()/t (demo/gpu_operator/main.cpp:171) summed over ranks.
+Inputs are resident in HBM before the timed region starts."""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def cpu_baseline(sample_n: int, p: int, reps: int = 2):
+    """The reference CPU operator (dense skernel, common/operators.hpp:113-133,
+    183-200) restated in oracle/wave_oracle.c, built with the reference's flags,
+    one thread per host core over a static cell partition with private y
+    (BASELINE.md section 3).  kind = "port"."""
+    import concurrent.futures as cf
+
+    import numpy as np
+    from oracle import wave_oracle as o
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    om = o.create_box(sample_n, p)
+    K = o.StiffnessOperator(om, p, {"c0": 1500.0}, fast=True)
+    X = o.dof_coordinates(om)
+    x = np.sin(2 * np.pi * X[:, 0])
+    nthreads = max(1, min(cores, om.ncells))
+    bounds = np.linspace(0, om.ncells, nthreads + 1).astype(int)
+    ys = [np.zeros(om.ndofs) for _ in range(nthreads)]
+
+    def work(i):
+        K(x, ys[i], cells=(int(bounds[i]), int(bounds[i + 1])))
+
+    times = []
+    with cf.ThreadPoolExecutor(nthreads) as ex:
+        for r in range(reps + 1):
+            for y in ys:
+                y[:] = 0.0
+            t0 = time.perf_counter()
+            list(ex.map(work, range(nthreads)))
+            y = np.sum(ys, axis=0)
+            times.append(time.perf_counter() - t0)
+    t = float(np.median(times[1:]))
+    return {
+        "value": om.ndofs / t, "unit": "dofs/s", "cores": nthreads, "kind": "port",
+        "sample": f"P{p} {sample_n}^3-cell box ({om.ndofs} dofs), dense reference skernel, "
+                  f"-Ofast -march=native, {reps} timed applies, median {t:.3f} s",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--size", type=int, default=54, help="cells per edge per GPU (reference flag --size)")
+    ap.add_argument("--degree", type=int, default=4, help="element degree (reference flag --degree)")
+    ap.add_argument("--generic", action="store_true", help="use the arbitrary-dofmap kernel instead of the box kernel")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=24)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import wave_fenics_amd as w
+    from wave_fenics_amd import la
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    p, n = args.degree, args.size
+    updater = None
+    if world == 1:
+        mesh = w.create_box(n)
+        V = w.create_functionspace(mesh, p, build_dofmap=args.generic)
+        V.structured = not args.generic
+        owned_global = V.ndofs
+        workload = f"P{p} hex box {n}^3 cells, {owned_global} dofs, stiffness + lumped-mass-inverse apply"
+        parallelism = "single"
+    else:
+        from wave_fenics_amd.distributed import create_distributed_box, VectorUpdater
+        part = create_distributed_box(n, p, world, rank)
+        mesh, V = part.mesh, part.V
+        V.structured = not args.generic
+        updater = VectorUpdater(part, device=dev)
+        owned_global = part.size_global
+        workload = (f"P{p} hex box, {part.procs[0]}x{part.procs[1]}x{part.procs[2]} partition, {n}^3 cells per GPU, "
+                    f"{owned_global} dofs, ghost fwd + stiffness + ghost rev(add) + lumped-mass-inverse apply")
+        parallelism = f"dd{world} ({part.procs[0]}x{part.procs[1]}x{part.procs[2]})"
+
+    K = w.StiffnessOperator(V, p, {"c0": 1500.0})
+    M = w.MassOperatorLumped(V, p)
+    N = V.ndofs
+    # synthetic input x = sin(2 pi X) at the dof coordinate (demo/gpu_operator/main.cpp:81), built on device
+    NX, NY, NZ = V.lattice
+    pts, _, _ = w.tabulate_gll(p)
+    ncx = (NX - 1) // p
+    xs = np.concatenate([(np.arange(ncx)[:, None] + pts[None, :p]).reshape(-1), [float(ncx)]]) / ncx
+    x0 = float(mesh.lo[0]); x1 = float(mesh.hi[0])
+    xs = x0 + (x1 - x0) * xs
+    x = torch.sin(2 * np.pi * torch.from_numpy(xs).to(dev)).repeat(NY * NZ).contiguous()
+    y = torch.zeros(N, dtype=torch.float64, device=dev)
+    kv = torch.zeros(N, dtype=torch.float64, device=dev)
+    m = torch.zeros(N, dtype=torch.float64, device=dev)
+    M(torch.ones(N, dtype=torch.float64, device=dev), m)
+    if updater is not None:
+        updater.scatter_rev(m)
+        updater.scatter_fwd(m)
+
+    def step(ev=None):
+        if updater is not None:
+            updater.scatter_fwd(x)
+        if ev is not None:
+            ev[0].record()
+        K(x, y)
+        if ev is not None:
+            ev[1].record()
+        if updater is not None:
+            updater.scatter_rev(y)
+        la.pointwise_div(y, m, kv)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(events[i])
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    # average duration of the dominant kernel (stiffness) from HIP events on its stream
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
+    assert bool(torch.isfinite(kv).all()), "non-finite result"
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        alg = K.alg_bytes()
+        achieved = alg / (kern_ms * 1e-3) / 1e9
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tp):
+            try:
+                with open(tp) as f:
+                    traffic = json.load(f).get("stiffness_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "dofs/sec stiffness-operator apply, P4 hex box mesh",
+            "value": owned_global / (elapsed / args.steps),
+            "unit": "dofs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": workload, "degree": p, "cells_per_gpu": int(mesh.ncells),
+                       "global_dofs": int(owned_global), "parallelism": parallelism,
+                       "kernel": "generic" if args.generic else "box"},
+            "roofline": {"bound": "hbm", "kernel": "stiffness apply", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "alg_bytes_per_launch": alg, "kernel_ms": kern_ms,
+                         "stiffness_only_dofs_per_s": V.ndofs / (kern_ms * 1e-3)},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                out["cpu_baseline"] = cpu_baseline(args.cpu_sample, p)
+            except Exception as e:  # the baseline is reported, never required for the GPU number
+                out["cpu_baseline"] = {"value": None, "unit": "dofs/s", "cores": 0, "kind": "port",
+                                       "sample": f"failed: {e}"}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,175 @@
+/*
+ * wavehip.h -- C ABI of libwavehip, the MI355X (gfx950) matrix-free operator
+ * engine for the explicit-RK wave loop of Excalibur-SLE/wave-fenics.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++/torch types,
+ * no exceptions.  Every entry point returns 0 on success or a negative
+ * wf_status; wf_last_error() returns the message of the last failure on the
+ * calling thread.  Each declaration cites the reference interface it replaces
+ * (paths relative to the reference root).
+ *
+ * Conventions
+ *   - fp64 data, int32 indices.
+ *   - "h_" parameters are host pointers read during the call (setup);
+ *     "d_" parameters are device pointers (hipMalloc / torch tensors).
+ *   - apply is y += A x (the reference accumulates, operators.hpp:196-198,
+ *     scatter.cu:43; the caller zeroes y, LinearGLL.hpp:173).
+ *   - stream is a hipStream_t passed as void* (NULL = default stream); all
+ *     device work is stream-ordered and asynchronous, nothing synchronises
+ *     except wf_sync and the setup calls that read host memory.
+ *   - element-local tensor ordering l = i + n*(j + n*k), n = P+1, i along x.
+ */
+#ifndef WAVEHIP_H
+#define WAVEHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  WF_OK = 0,
+  WF_ERR_INVALID = -1,     /* bad argument                                      */
+  WF_ERR_UNSUPPORTED = -2, /* e.g. degree outside 1..7 (mass.hpp:91-92 throws)  */
+  WF_ERR_HIP = -3,         /* a HIP runtime call failed (array.hpp:15-17 throws) */
+  WF_ERR_NODEVICE = -4     /* fewer devices than requested (utils.hpp:30-34)     */
+} wf_status;
+
+typedef struct wf_op wf_op;
+
+const char* wf_last_error(void);
+const char* wf_version(void);
+
+/* ---- device runtime shims: common/cuda/utils.hpp:22-56, array.hpp:8-51 ---- */
+int wf_device_count(int* count);
+int wf_set_device(int device);                       /* utils::set_device      */
+int wf_device_info(int device, char* name, size_t name_len, size_t* total_mem,
+                   int* num_cu);                     /* utils::output_device_info */
+int wf_malloc(void** d_ptr, size_t bytes);           /* cuda::array ctor       */
+int wf_free(void* d_ptr);                            /* cuda::array dtor       */
+int wf_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes); /* array::set */
+int wf_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes); /* copy_to_host */
+int wf_memset(void* d_dst, int value, size_t bytes, void* stream);
+int wf_sync(void* stream);                           /* cudaDeviceSynchronize  */
+
+/* ---- a1/a13: tabulation (host) ------------------------------------------
+ * common/operators.hpp:13-32 tabulate_basis_and_permutation,
+ * common/precompute.hpp:179-189 tabulate_1d.
+ * 1-D GLL rule with P+1 points on [0,1] and the collocation derivative matrix
+ * D[q*n + a] = l_a'(xi_q), clamped to -1/0/1 like the reference's dense table.
+ * Any output pointer may be NULL. */
+int wf_tabulate_gll(int P, double* h_points, double* h_weights, double* h_D);
+
+/* Dense reference-layout table[4][nq][nd] (0 = values, 1..3 = d/dx,d/dy,d/dz),
+ * nq = nd = (P+1)^3, tensor ordering, clamped (operators.hpp:23-29). */
+int wf_tabulate_dense(int P, double* h_table);
+
+/* common/permute.hpp:10-27 reorder_dofmap: out[c*nd + k] = in[c*nd + perm[k]]. */
+int wf_reorder_dofmap(int ncells, int nd, const int32_t* h_perm,
+                      const int32_t* h_in, int32_t* h_out);
+
+/* ---- a2/a13: geometry (device kernel, host in/out) -----------------------
+ * common/precomputation.hpp:18-110 precompute_geometric_data (use_fabs = 1,
+ * clamp = 1) and common/precompute.hpp:49-176 (use_fabs = 0, clamp = 0).
+ * h_xverts [nverts][3], h_geom_dofmap [ncells][8] (vertex v = a + 2b + 4c).
+ * Outputs in the reference layout: h_G [ncells][nq][3][3] (may be NULL),
+ * h_detJ [ncells][nq] (may be NULL); quadrature = (P+1)^3 GLL points. */
+int wf_geometry_hex(int P, int ncells, int nverts, const double* h_xverts,
+                    const int32_t* h_geom_dofmap, int use_fabs, int clamp,
+                    double* h_G, double* h_detJ);
+
+/* ---- operators -----------------------------------------------------------*/
+typedef enum {
+  WF_OP_STIFFNESS = 0,   /* StiffnessOperator      common/operators.hpp:137-201 */
+  WF_OP_MASS_LUMPED = 1, /* MassOperatorCPU / SpectralMassOperator
+                            common/operators.hpp:44-109, cuda/spectral_mass.hpp:24-100 */
+  WF_OP_MASS_DENSE = 2   /* MassOperator (Phi^T D Phi) common/cuda/mass.hpp:18-107    */
+} wf_op_kind;
+
+typedef enum {
+  WF_FLAG_NONE = 0,
+  WF_FLAG_NO_FABS = 1,     /* detJ keeps its sign (spectral_mass.hpp:58-64)    */
+  WF_FLAG_NO_CLAMP = 2     /* skip the -1/0/1 clamp of G                        */
+} wf_flags;
+
+typedef struct {
+  int kind;                    /* wf_op_kind                                    */
+  int degree;                  /* P in 1..7, hexahedron, nd = (P+1)^3           */
+  int ncells;                  /* local cells (operators.hpp:153)                */
+  int ndofs;                   /* length of x and y: owned + ghost dofs          */
+  const int32_t* h_dofmap;     /* [ncells][nd], element ordering                 */
+  const int32_t* h_perm;       /* tensor -> element ordering (the reference's
+                                  `perm`, operators.hpp:24); NULL = identity      */
+  /* geometry: either precomputed arrays in the reference layout ...            */
+  const double* h_G;           /* [ncells][nq][3][3] (stiffness) or NULL         */
+  const double* h_detJ;        /* [ncells][nq] (mass) or NULL                    */
+  /* ... or the mesh, in which case the geometry is computed on the device      */
+  int nverts;
+  const double* h_xverts;      /* [nverts][3]                                    */
+  const int32_t* h_geom_dofmap;/* [ncells][8]                                    */
+  double c0;                   /* speed of sound; stiffness carries -c0^2
+                                  (operators.hpp:114-115; reference fixes 1500)   */
+  int flags;                   /* wf_flags                                       */
+  /* WF_OP_MASS_DENSE only: 1-D interpolation matrix phi1[nq1][P+1] (row-major)
+   * of a tensor-product rule; h_detJ is then [ncells][nq1^3].                   */
+  int nq1;
+  const double* h_phi1;
+} wf_op_desc;
+
+/* Op(V, degree[, params]) constructors: operators.hpp:53,149; mass.hpp:20;
+ * spectral_mass.hpp:26.  Copies every host array; owns all device state. */
+int wf_op_create(const wf_op_desc* desc, wf_op** out);
+
+/* Structured box mesh (mesh::create_box, demo/gpu_operator/main.cpp:60-63) with
+ * this engine's lexicographic numbering: vertex (a,b,c) -> a + (nx+1)(b + (ny+1)c),
+ * dof (I,J,K) -> I + NX*(J + NY*K), NX = P*nx+1 ...  The dofmap is implicit
+ * (never read from memory) and the geometry is computed on the device from
+ * h_xverts [(nx+1)(ny+1)(nz+1)][3]. */
+int wf_op_create_box(int kind, int degree, int nx, int ny, int nz,
+                     const double* h_xverts, double c0, int flags, wf_op** out);
+
+/* op(x, y) / op.apply(x, y): y += A x.  operators.hpp:183, mass.hpp:76,
+ * spectral_mass.hpp:84. */
+int wf_op_apply(wf_op* op, const double* d_x, double* d_y, void* stream);
+
+typedef struct {
+  int kind, degree, num_cells, num_dofs_cell, num_quads, ndofs, structured;
+  double flops;          /* reference model 4*ncells*nq*nd (mass.hpp:71)        */
+  double alg_bytes;      /* algorithmic HBM bytes per apply          */
+  size_t device_bytes;   /* device memory owned by the operator                  */
+} wf_op_info_t;
+int wf_op_info(const wf_op* op, wf_op_info_t* info); /* num_quads()/num_cells()/... mass.hpp:68-71 */
+int wf_op_destroy(wf_op* op);
+
+/* ---- a8/a9: free kernels --------------------------------------------------
+ * common/cuda/scatter.hpp:7-14, transform.hpp:7-8 (the reference passes a block
+ * size; launch geometry is internal here). */
+int wf_gather(int32_t N, const int32_t* d_indices, const double* d_in, double* d_out, void* stream);      /* out[i] = in[indices[i]]   */
+int wf_scatter_add(int32_t N, const int32_t* d_indices, const double* d_in, double* d_out, void* stream); /* out[indices[i]] += in[i]  */
+int wf_scatter_set(int32_t N, const int32_t* d_indices, const double* d_in, double* d_out, void* stream); /* out[indices[i]]  = in[i]  (VectorUpdater.hpp:141 unpack) */
+int wf_transform1(int32_t N, const double* d_in, const double* d_detJ, double* d_out, void* stream);      /* out[i] = in[i]*detJ[i]    */
+
+/* ---- a15/a16: vector kernels of the RK4 loop ------------------------------
+ * common/LinearGLL.hpp:17-33 (copy, axpy), :173 (fill), :182-191 (divide),
+ * common/cuda/la.hpp:31-138. */
+int wf_copy(int64_t n, const double* d_in, double* d_out, void* stream);
+int wf_fill(int64_t n, double value, double* d_out, void* stream);
+int wf_axpy(int64_t n, double alpha, const double* d_x, const double* d_y, double* d_r, void* stream); /* r = alpha*x + y */
+int wf_scale(int64_t n, double alpha, double* d_x, void* stream);
+int wf_pointwise_div(int64_t n, const double* d_b, const double* d_m, double* d_out, void* stream);    /* out = b / m */
+int wf_pointwise_mult_add(int64_t n, const double* d_m, const double* d_x, double* d_y, void* stream); /* y += m .* x */
+int wf_dot(int64_t n, const double* d_x, const double* d_y, double* d_result, void* stream);           /* la.hpp:87 inner_product; result on device */
+
+/* ---- a7: boundary operator (diagonal form of forms.ufl:19-24) -------------
+ * b[idx1[i]] += s1 * m1[i];  b[idx2[i]] += s2 * m2[i] * v[idx2[i]].
+ * LinearGLL.hpp:175 with s1 = c0^2 g(t), s2 = -c0. */
+int wf_boundary_apply(int32_t n1, const int32_t* d_idx1, const double* d_m1, double s1,
+                      int32_t n2, const int32_t* d_idx2, const double* d_m2, double s2,
+                      const double* d_v, double* d_b, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WAVEHIP_H */

@@ -1,0 +1,334 @@
+"""GPU parity tests: libwavehip (through the C ABI, via wave_fenics_amd) against
+the CPU oracle on the same seeded inputs.  Run on the GPU box: pytest -m gpu.
+
+Tolerance (SURVEY.md 8c / BASELINE.json): fp64; single operator apply
+  max|y_gpu - y_ref| <= 1e-12 * max|y_ref|
+(dense reference summation order vs sum-factorised order + atomic ordering);
+integer/index work (gather) is bit-exact."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-12
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    import wave_fenics_amd as w
+    w.lib()
+    return torch.device("cuda", 0)
+
+
+def dev(a, gpu, dtype=None):
+    import torch
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(gpu)
+    return t if dtype is None else t.to(dtype)
+
+
+def relerr(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def make(oracle, n, p, perturb=0.2):
+    import wave_fenics_amd as w
+    om = oracle.create_box(n, p, perturb=perturb)
+    mesh = w.create_box(n, perturb=perturb)
+    V = w.create_functionspace(mesh, p)
+    assert np.array_equal(V.dofmap, om.dofmap) and np.array_equal(mesh.x, om.x)
+    return om, mesh, V
+
+
+@pytest.mark.parametrize("p,n", [(1, (5, 4, 3)), (2, (4, 3, 3)), (3, (3, 3, 2)), (4, (3, 2, 2)), (4, (6, 5, 1)),
+                                 (5, (2, 2, 2)), (6, (2, 2, 1)), (7, (2, 1, 1))])
+def test_stiffness_generic_vs_oracle(gpu, oracle, p, n):
+    import wave_fenics_amd as w
+    om, mesh, V = make(oracle, n, p)
+    K = oracle.StiffnessOperator(om, p)
+    rng = np.random.default_rng(1234)
+    x = rng.uniform(-1, 1, om.ndofs)
+    y0 = rng.uniform(-1, 1, om.ndofs) * 1e6          # accumulate semantics: y += K x
+    yref = y0.copy()
+    K(x, yref)
+    # (a) geometry handed over in the reference layout (isolates the kernel)
+    op = w.StiffnessOperator(V, p, {"c0": 1500.0}, G=K.G, structured=False)
+    y = dev(y0, gpu)
+    op(dev(x, gpu), y)
+    assert relerr(y.cpu().numpy(), yref) <= TOL
+    # (b) geometry computed on the device from the mesh
+    op2 = w.StiffnessOperator(V, p, {"c0": 1500.0}, structured=False)
+    y2 = dev(y0, gpu)
+    op2(dev(x, gpu), y2)
+    assert relerr(y2.cpu().numpy(), yref) <= 1e-11
+    assert op.num_cells() == om.ncells and op.num_dofs() == (p + 1) ** 3 and op.num_quads() == (p + 1) ** 3
+
+
+def test_stiffness_generic_permuted_dofmap(gpu, oracle):
+    """Arbitrary (non-lexicographic) global numbering and a non-identity
+    element permutation, as a DOLFINx dofmap would present them
+    (common/permute.hpp:10-27)."""
+    import wave_fenics_amd as w
+    p, n = 3, (3, 2, 2)
+    om, mesh, V = make(oracle, n, p)
+    rng = np.random.default_rng(7)
+    gperm = rng.permutation(om.ndofs).astype(np.int32)        # renumber global dofs
+    eperm = rng.permutation((p + 1) ** 3).astype(np.int32)    # tensor -> element order
+    inv = np.empty_like(eperm)
+    inv[eperm] = np.arange(eperm.size, dtype=np.int32)
+    dm_elem = gperm[om.dofmap][:, inv]                         # element-ordered dofmap
+    assert np.array_equal(dm_elem[:, eperm], gperm[om.dofmap])
+    K = oracle.StiffnessOperator(om, p)
+    x = rng.uniform(-1, 1, om.ndofs)
+    yref = np.zeros(om.ndofs)
+    K(x, yref)
+    Vp = w.FunctionSpace(mesh, p, dm_elem.astype(np.int32), w.IndexMap(om.ndofs), V.lattice, structured=False)
+    op = w.StiffnessOperator(Vp, p, G=K.G, perm=eperm)
+    xp = np.empty_like(x)
+    xp[gperm] = x
+    y = dev(np.zeros(om.ndofs), gpu)
+    op(dev(xp, gpu), y)
+    assert relerr(y.cpu().numpy()[gperm], yref) <= TOL
+
+
+@pytest.mark.parametrize("p,n,block", [(4, (5, 4, 3), "5,2,1"), (4, (5, 4, 3), "2,2,2"), (4, (7, 3, 2), "3,3,1"),
+                                       (4, (4, 4, 4), "1,1,1"), (2, (7, 5, 4), "3,3,3"), (3, (5, 4, 3), "4,2,2"),
+                                       (1, (9, 5, 5), "4,4,4"), (5, (3, 2, 2), "7,1,1"), (6, (3, 2, 2), "5,1,1"),
+                                       (7, (2, 2, 1), "2,2,1")])
+def test_stiffness_box_vs_oracle(gpu, oracle, p, n, block, monkeypatch):
+    """Structured (implicit dofmap) kernel incl. partial blocks at the mesh end."""
+    import wave_fenics_amd as w
+    monkeypatch.setenv("WF_BOX_BLOCK", block)
+    om, mesh, V = make(oracle, n, p)
+    K = oracle.StiffnessOperator(om, p)
+    rng = np.random.default_rng(99)
+    x = rng.uniform(-1, 1, om.ndofs)
+    y0 = rng.uniform(-1, 1, om.ndofs) * 1e6
+    yref = y0.copy()
+    K(x, yref)
+    op = w.StiffnessOperator(V, p, {"c0": 1500.0}, structured=True)
+    assert op.info.structured == 1
+    y = dev(y0, gpu)
+    op(dev(x, gpu), y)
+    assert relerr(y.cpu().numpy(), yref) <= 1e-11
+
+
+def test_geometry_vs_oracle(gpu, oracle):
+    import wave_fenics_amd as w
+    for p, n in [(2, (3, 3, 2)), (4, (2, 2, 2))]:
+        om, mesh, V = make(oracle, n, p)
+        Gr, dr = oracle.precompute_geometric_data(om, p)
+        G, d = w.precompute_geometric_data(mesh, p)
+        assert relerr(d, dr) <= 1e-14
+        assert np.abs(G - Gr).max() <= 1e-14 * np.abs(Gr).max()
+        # affine mesh: exact zeros off the diagonal after the clamp
+        om, mesh, V = make(oracle, n, p, perturb=0.0)
+        G, d = w.precompute_geometric_data(mesh, p)
+        assert np.all(G[:, :, 0, 1] == 0.0) and np.all(G[:, :, 1, 2] == 0.0)
+
+
+@pytest.mark.parametrize("p,n", [(2, (4, 3, 3)), (4, (3, 2, 2)), (6, (2, 2, 1))])
+def test_lumped_mass_vs_oracle(gpu, oracle, p, n):
+    import wave_fenics_amd as w
+    om, mesh, V = make(oracle, n, p)
+    M = oracle.MassOperatorCPU(om, p)
+    rng = np.random.default_rng(5)
+    x = rng.uniform(-1, 1, om.ndofs)
+    y0 = rng.uniform(-1, 1, om.ndofs)
+    yref = y0.copy()
+    M(x, yref)
+    for structured in (False, True):
+        op = w.MassOperatorLumped(V, p, structured=structured)
+        y = dev(y0, gpu)
+        op(dev(x, gpu), y)
+        assert relerr(y.cpu().numpy(), yref) <= 1e-13
+    # handed-over detJ (reference layout)
+    op = w.MassOperatorLumped(V, p, detJ=M.detJ, structured=False)
+    y = dev(y0, gpu)
+    op.apply(dev(x, gpu), y)
+    assert relerr(y.cpu().numpy(), yref) <= 1e-14
+
+
+def test_spectral_mass_x_ones(gpu, oracle):
+    """The reference's own check procedure: x = 1, |y_gpu - y_cpu| <= 1e-8 abs
+    (demo/gpu_operator_monolithic/main.cpp:102-118) -- here to 1e-13 relative."""
+    import wave_fenics_amd as w
+    p, n = 6, (2, 2, 2)
+    om, mesh, V = make(oracle, n, p)
+    M = oracle.MassOperatorCPU(om, p)
+    yref = np.zeros(om.ndofs)
+    M(np.ones(om.ndofs), yref)
+    for structured in (False, True):
+        op = w.SpectralMassOperator(V, p, structured=structured)
+        y = dev(np.zeros(om.ndofs), gpu)
+        op.apply(dev(np.ones(om.ndofs), gpu), y)
+        got = y.cpu().numpy()
+        assert np.abs(got - yref).max() <= 1e-8
+        assert relerr(got, yref) <= 1e-13
+    with pytest.raises(w.WavehipError):
+        w.SpectralMassOperator(V, 1)
+
+
+@pytest.mark.parametrize("p,variant,quad,qd", [(1, "gll", "gll", 1), (2, "gll", "gll", 3), (3, "gll", "gll", 4),
+                                                (2, "equispaced", "gauss_jacobi", 4),
+                                                (3, "equispaced", "gauss_jacobi", 6),
+                                                (4, "equispaced", "gauss_jacobi", 8)])
+def test_dense_mass_vs_oracle(gpu, oracle, p, variant, quad, qd):
+    """MassOperator (common/cuda/mass.hpp) incl. the non-collocated cuBLAS-demo
+    configuration (demo/gpu_operator/main.cpp:66-68,96-99)."""
+    import wave_fenics_amd as w
+    n = (3, 2, 2)
+    om, mesh, V = make(oracle, n, p)
+    pts, wts, phi1, phi, X, W = oracle.tabulate_mass_tables(p, variant, quad, qd)
+    detJ = oracle.compute_detJ_generic(om, X, W)
+    rng = np.random.default_rng(11)
+    x = rng.uniform(-1, 1, om.ndofs)
+    yref = np.zeros(om.ndofs)
+    oracle.dense_mass_apply(om, phi, detJ, x, yref)
+    op = w.MassOperator(V, p, phi1, detJ)
+    y = dev(np.zeros(om.ndofs), gpu)
+    op.apply(dev(x, gpu), y)
+    assert relerr(y.cpu().numpy(), yref) <= TOL
+    assert op.flops() == 4.0 * om.ncells * phi.shape[0] * phi.shape[1]
+
+
+def test_gather_scatter_transform(gpu, oracle):
+    """demo/gpu_scatter_local/main.cpp:70,84-90: gather(iota) == dofmap, exactly."""
+    import torch
+    import wave_fenics_amd as w
+    p, n = 3, (4, 3, 2)
+    om, mesh, V = make(oracle, n, p)
+    Ne = om.dofmap.size
+    idx = dev(om.dofmap.reshape(-1), gpu)
+    x = torch.arange(om.ndofs, dtype=torch.float64, device=gpu)
+    xe = torch.zeros(Ne, dtype=torch.float64, device=gpu)
+    w.gather(Ne, idx, x, xe, 512)
+    assert np.array_equal(xe.cpu().numpy(), om.dofmap.reshape(-1).astype(np.float64))
+    # scatter-add of integer-valued data is exact in any order
+    y = torch.zeros(om.ndofs, dtype=torch.float64, device=gpu)
+    w.scatter(Ne, idx, xe, y, 512)
+    ref = np.zeros(om.ndofs)
+    np.add.at(ref, om.dofmap.reshape(-1), om.dofmap.reshape(-1).astype(np.float64))
+    assert np.array_equal(y.cpu().numpy(), ref)
+    d = dev(np.random.default_rng(0).uniform(0.5, 2, Ne), gpu)
+    out = torch.zeros_like(xe)
+    w.transform1(Ne, xe, d, out, 512)
+    assert np.array_equal(out.cpu().numpy(), xe.cpu().numpy() * d.cpu().numpy())
+    # empty input
+    w.gather(0, idx, x, xe)
+    w.scatter(0, idx, xe, y)
+
+
+def test_la_kernels(gpu):
+    import torch
+    from wave_fenics_amd import la
+    rng = np.random.default_rng(3)
+    n, nl = 100003, 90001
+    a, b = rng.uniform(-1, 1, n), rng.uniform(0.5, 2, n)
+    x, y = dev(a, gpu), dev(b, gpu)
+    r = torch.zeros_like(x)
+    la.axpy(r, 0.37, x, y, nl)
+    ref = np.zeros(n)
+    ref[:nl] = a[:nl] * 0.37 + b[:nl]
+    assert np.array_equal(r.cpu().numpy(), ref)
+    la.axpy(y, 0.5, x, y, nl)                      # aliasing r == y as LinearGLL.hpp:253
+    ref2 = b.copy()
+    ref2[:nl] = a[:nl] * 0.5 + b[:nl]
+    assert np.array_equal(y.cpu().numpy(), ref2)
+    out = torch.zeros_like(x)
+    la.pointwise_div(x, y, out)
+    assert np.array_equal(out.cpu().numpy(), a / ref2)
+    la.fill(out, 2.5)
+    assert np.all(out.cpu().numpy() == 2.5)
+    la.copy(x, out)
+    assert np.array_equal(out.cpu().numpy(), a)
+    assert abs(la.inner_product(x, y, nl) - np.dot(a[:nl], ref2[:nl])) <= 1e-12 * nl
+    la.scale(2.0, out)
+    assert np.array_equal(out.cpu().numpy(), 2 * a)
+
+
+def test_error_behaviour(gpu, oracle):
+    import wave_fenics_amd as w
+    om, mesh, V = make(oracle, (2, 2, 2), 2)
+    with pytest.raises(w.WavehipError):
+        w.StiffnessOperator(V, 8, structured=False)             # unsupported degree (mass.hpp:91-92)
+    bad = V.dofmap.copy()
+    bad[0, 0] = om.ndofs                                          # out-of-range dof index
+    Vb = w.FunctionSpace(mesh, 2, bad, w.IndexMap(om.ndofs), V.lattice, structured=False)
+    with pytest.raises(w.WavehipError):
+        w.StiffnessOperator(Vb, 2)
+    import torch
+    op = w.StiffnessOperator(V, 2)
+    short = torch.zeros(5, dtype=torch.float64, device=gpu)
+    with pytest.raises(w.WavehipError):
+        op(short, short)
+
+
+def test_full_size_properties(gpu):
+    """BASELINE cfg2 (P4, 54^3 cells, 10 218 313 dofs): size-independent
+    properties at full size -- K 1 = 0, x^T K x = -c0^2 |Omega| for x = X,
+    symmetry u^T K v = v^T K u, linearity, generic == structured."""
+    import torch
+    import wave_fenics_amd as w
+    p, N = 4, 54
+    mesh = w.create_box(N, perturb=0.0)
+    V = w.create_functionspace(mesh, p)
+    op = w.StiffnessOperator(V, p, {"c0": 1500.0}, structured=True)
+    n = V.ndofs
+    assert n == 10218313
+    c02 = 1500.0 ** 2
+    y = torch.zeros(n, dtype=torch.float64, device=gpu)
+    op(torch.ones(n, dtype=torch.float64, device=gpu), y)
+    assert float(y.abs().max()) <= 1e-10 * c02
+    NX = V.lattice[0]
+    pts, _, _ = w.tabulate_gll(p)
+    xs = (np.repeat(np.arange(N), p)[:, None] + pts[None, :p]).reshape(-1)[: N * p]
+    xs = np.concatenate([(np.arange(N)[:, None] + pts[None, :p]).reshape(-1), [float(N)]]) / N
+    X = torch.from_numpy(xs).to(gpu).repeat(V.lattice[1] * V.lattice[2])
+    y.zero_()
+    op(X, y)
+    assert abs(float(torch.dot(X, y)) / (-c02) - 1.0) <= 1e-11
+    g = torch.Generator(device=gpu).manual_seed(1)
+    u = torch.rand(n, dtype=torch.float64, device=gpu, generator=g) - 0.5
+    v = torch.rand(n, dtype=torch.float64, device=gpu, generator=g) - 0.5
+    Ku, Kv, Kuv = torch.zeros_like(u), torch.zeros_like(u), torch.zeros_like(u)
+    op(u, Ku)
+    op(v, Kv)
+    a, b = float(torch.dot(v, Ku)), float(torch.dot(u, Kv))
+    assert abs(a - b) <= 1e-11 * abs(a)
+    op(2.0 * u - 3.0 * v, Kuv)
+    assert float((Kuv - (2.0 * Ku - 3.0 * Kv)).abs().max()) <= 1e-11 * float(Kuv.abs().max())
+    # generic kernel on the same mesh through the explicit dofmap
+    opg = w.StiffnessOperator(V, p, {"c0": 1500.0}, structured=False)
+    Kg = torch.zeros_like(u)
+    opg(u, Kg)
+    assert float((Kg - Ku).abs().max()) <= 1e-11 * float(Ku.abs().max())
+
+
+def test_rk4_cfg1_vs_oracle(gpu, oracle):
+    """BASELINE cfg1: P2 box, 18^3 cells (50 653 dofs), 100 RK4 steps from rest,
+    Gamma_1 = face x=0, Gamma_2 = the rest; tolerance 1e-9 relative on u and v
+    (SURVEY 8c).  CFL 0.25, see tests/test_oracle_kat.py::test_rk4_runs_and_is_stable."""
+    import wave_fenics_amd as w
+    from wave_fenics_amd.linear_gll import LinearGLLOpt, cfl_time_step
+    p, N = 2, 18
+    hi = (0.01, 0.01, 0.01)
+    om = oracle.create_box(N, p, hi=hi)
+    ref = oracle.LinearGLLOpt(om, p, 1500.0, 0.5e6, 6e4)
+    dt, _ = oracle.cfl_time_step(om, p, 1500.0, 0.5e6, CFL=0.25)
+    ref.init()
+    ref.rk4(0.0, 100 * dt - 1e-13, dt)
+    mesh = w.create_box(N, hi=hi)
+    V = w.create_functionspace(mesh, p)
+    dt2, _ = cfl_time_step(mesh, p, 1500.0, 0.5e6, CFL=0.25)
+    assert dt2 == dt
+    for structured in (True, False):
+        eqn = LinearGLLOpt(V, p, 1500.0, 0.5e6, 6e4, structured=structured)
+        eqn.init()
+        t, steps = eqn.rk4(0.0, 100 * dt - 1e-13, dt)
+        assert steps == 100
+        assert relerr(eqn.u_n.cpu().numpy(), ref.u_n) <= 1e-9
+        assert relerr(eqn.v_n.cpu().numpy(), ref.v_n) <= 1e-9

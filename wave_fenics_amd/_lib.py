@@ -1,0 +1,100 @@
+"""ctypes binding of libwavehip.so (the C ABI of include/wavehip.h)."""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_int, c_int32, c_int64, c_size_t, c_void_p
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libwavehip.so")
+
+
+class WavehipError(RuntimeError):
+    """Mirrors the std::runtime_error the reference throws on device failures
+    (common/cuda/array.hpp:15-17, mass.hpp:91-92, utils.hpp:30-34)."""
+
+
+class OpDesc(ctypes.Structure):
+    _fields_ = [
+        ("kind", c_int), ("degree", c_int), ("ncells", c_int), ("ndofs", c_int),
+        ("h_dofmap", POINTER(c_int32)), ("h_perm", POINTER(c_int32)),
+        ("h_G", POINTER(c_double)), ("h_detJ", POINTER(c_double)),
+        ("nverts", c_int), ("h_xverts", POINTER(c_double)), ("h_geom_dofmap", POINTER(c_int32)),
+        ("c0", c_double), ("flags", c_int),
+        ("nq1", c_int), ("h_phi1", POINTER(c_double)),
+    ]
+
+
+class OpInfo(ctypes.Structure):
+    _fields_ = [
+        ("kind", c_int), ("degree", c_int), ("num_cells", c_int), ("num_dofs_cell", c_int),
+        ("num_quads", c_int), ("ndofs", c_int), ("structured", c_int),
+        ("flops", c_double), ("alg_bytes", c_double), ("device_bytes", c_size_t),
+    ]
+
+
+WF_OP_STIFFNESS, WF_OP_MASS_LUMPED, WF_OP_MASS_DENSE = 0, 1, 2
+WF_FLAG_NONE, WF_FLAG_NO_FABS, WF_FLAG_NO_CLAMP = 0, 1, 2
+
+# every symbol include/wavehip.h declares: name -> (restype, argtypes)
+_dp, _ip, _vp = POINTER(c_double), POINTER(c_int32), c_void_p
+SIGNATURES = {
+    "wf_last_error": (c_char_p, []),
+    "wf_version": (c_char_p, []),
+    "wf_device_count": (c_int, [POINTER(c_int)]),
+    "wf_set_device": (c_int, [c_int]),
+    "wf_device_info": (c_int, [c_int, c_char_p, c_size_t, POINTER(c_size_t), POINTER(c_int)]),
+    "wf_malloc": (c_int, [POINTER(c_void_p), c_size_t]),
+    "wf_free": (c_int, [c_void_p]),
+    "wf_memcpy_h2d": (c_int, [c_void_p, c_void_p, c_size_t]),
+    "wf_memcpy_d2h": (c_int, [c_void_p, c_void_p, c_size_t]),
+    "wf_memset": (c_int, [c_void_p, c_int, c_size_t, c_void_p]),
+    "wf_sync": (c_int, [c_void_p]),
+    "wf_tabulate_gll": (c_int, [c_int, _dp, _dp, _dp]),
+    "wf_tabulate_dense": (c_int, [c_int, _dp]),
+    "wf_reorder_dofmap": (c_int, [c_int, c_int, _ip, _ip, _ip]),
+    "wf_geometry_hex": (c_int, [c_int, c_int, c_int, _dp, _ip, c_int, c_int, _dp, _dp]),
+    "wf_op_create": (c_int, [POINTER(OpDesc), POINTER(c_void_p)]),
+    "wf_op_create_box": (c_int, [c_int, c_int, c_int, c_int, c_int, _dp, c_double, c_int, POINTER(c_void_p)]),
+    "wf_op_apply": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "wf_op_info": (c_int, [c_void_p, POINTER(OpInfo)]),
+    "wf_op_destroy": (c_int, [c_void_p]),
+    "wf_gather": (c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "wf_scatter_add": (c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "wf_scatter_set": (c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "wf_transform1": (c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "wf_copy": (c_int, [c_int64, c_void_p, c_void_p, c_void_p]),
+    "wf_fill": (c_int, [c_int64, c_double, c_void_p, c_void_p]),
+    "wf_axpy": (c_int, [c_int64, c_double, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "wf_scale": (c_int, [c_int64, c_double, c_void_p, c_void_p]),
+    "wf_pointwise_div": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "wf_pointwise_mult_add": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "wf_dot": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "wf_boundary_apply": (c_int, [c_int32, c_void_p, c_void_p, c_double, c_int32, c_void_p, c_void_p, c_double,
+                                  c_void_p, c_void_p, c_void_p]),
+}
+
+_LIB = None
+
+
+def lib():
+    """Load libwavehip.so.  Raises (never falls back) when it is missing."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise WavehipError(
+                f"{LIB_PATH} not found: build it with `python -m wave_fenics_amd.build` "
+                "(there is no CPU fallback for the operator path)")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)          # AttributeError if the library lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = L
+    return _LIB
+
+
+def check(rc: int):
+    if rc != 0:
+        msg = lib().wf_last_error().decode(errors="replace")
+        raise WavehipError(f"libwavehip error {rc}: {msg}")

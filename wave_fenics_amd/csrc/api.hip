@@ -1,0 +1,458 @@
+// C ABI of libwavehip: device shims, geometry setup, operator handles.
+// See include/wavehip.h for the reference interface each entry point replaces.
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+
+#include "common.h"
+
+using namespace wf;
+
+struct wf_op {
+  int kind = 0, P = 0, n = 0, nd = 0, nq = 0, ncells = 0, ndofs = 0;
+  int structured = 0, nx = 0, ny = 0, nz = 0, bx = 1, by = 1, bz = 1;
+  int nq1 = 0;
+  double coeff = 0.0;
+  DMat dm{};
+  int32_t* d_dofmap = nullptr;
+  double* d_G6blk = nullptr;
+  double* d_detJ = nullptr;
+  double* d_D = nullptr;
+  double* d_phi1 = nullptr;
+  double* d_mdiag = nullptr;
+  size_t device_bytes = 0;
+};
+
+namespace {
+
+template <typename T>
+int dev_alloc(T** p, size_t count, size_t* total)
+{
+  *p = nullptr;
+  if (count == 0) return WF_OK;
+  WF_HIP_CHECK(hipMalloc((void**)p, count * sizeof(T)));
+  if (total) *total += count * sizeof(T);
+  return WF_OK;
+}
+
+template <typename T>
+int dev_upload(T** p, const T* host, size_t count, size_t* total)
+{
+  int rc = dev_alloc(p, count, total);
+  if (rc != WF_OK) return rc;
+  if (count) WF_HIP_CHECK(hipMemcpy(*p, host, count * sizeof(T), hipMemcpyHostToDevice));
+  return WF_OK;
+}
+
+// temporary device buffer freed at scope exit
+template <typename T>
+struct Scratch {
+  T* p = nullptr;
+  ~Scratch()
+  {
+    if (p) (void)hipFree(p);
+  }
+};
+
+void free_op(wf_op* op)
+{
+  if (!op) return;
+  (void)hipFree(op->d_dofmap);
+  (void)hipFree(op->d_G6blk);
+  (void)hipFree(op->d_detJ);
+  (void)hipFree(op->d_D);
+  (void)hipFree(op->d_phi1);
+  (void)hipFree(op->d_mdiag);
+  delete op;
+}
+
+int upload_tables(int P, Scratch<double>& d_pts, Scratch<double>& d_wts)
+{
+  const int n = P + 1;
+  std::vector<double> pts(n), wts(n);
+  gll_points_weights(n, pts.data(), wts.data());
+  int rc = dev_upload(&d_pts.p, pts.data(), n, nullptr);
+  if (rc != WF_OK) return rc;
+  return dev_upload(&d_wts.p, wts.data(), n, nullptr);
+}
+
+void default_box_block(int P, int* bx, int* by, int* bz)
+{
+  switch (P) {
+    case 1: *bx = 4; *by = 4; *bz = 4; break;
+    case 2: *bx = 3; *by = 3; *bz = 3; break;
+    case 3: *bx = 4; *by = 2; *bz = 2; break;
+    case 4: *bx = 5; *by = 2; *bz = 1; break;
+    case 5: *bx = 7; *by = 1; *bz = 1; break;
+    case 6: *bx = 5; *by = 1; *bz = 1; break;
+    default: *bx = 4; *by = 1; *bz = 1; break;
+  }
+  // tuning hook: WF_BOX_BLOCK="bx,by,bz"
+  if (const char* e = std::getenv("WF_BOX_BLOCK")) {
+    int a, b, c;
+    if (std::sscanf(e, "%d,%d,%d", &a, &b, &c) == 3 && a > 0 && b > 0 && c > 0
+        && a * b * c * (P + 1) * (P + 1) <= 256) {
+      *bx = a;
+      *by = b;
+      *bz = c;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+// ---- device runtime shims ------------------------------------------------
+int wf_device_count(int* count)
+{
+  WF_REQUIRE(count != nullptr, "wf_device_count: null output");
+  hipError_t e = hipGetDeviceCount(count);
+  if (e != hipSuccess) {
+    *count = 0;
+    set_error(std::string("hipGetDeviceCount failed: ") + hipGetErrorString(e));
+    return WF_ERR_NODEVICE;
+  }
+  return WF_OK;
+}
+
+int wf_set_device(int device)
+{
+  int count = 0;
+  int rc = wf_device_count(&count);
+  if (rc != WF_OK) return rc;
+  if (device < 0 || device >= count) {
+    // utils.hpp:30-34: "The number of MPI processes should be less or equal the number of available devices"
+    set_error("wf_set_device: device " + std::to_string(device) + " not available (" + std::to_string(count)
+              + " devices)");
+    return WF_ERR_NODEVICE;
+  }
+  WF_HIP_CHECK(hipSetDevice(device));
+  return WF_OK;
+}
+
+int wf_device_info(int device, char* name, size_t name_len, size_t* total_mem, int* num_cu)
+{
+  hipDeviceProp_t prop;
+  WF_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+  if (name && name_len) {
+    std::strncpy(name, prop.name, name_len - 1);
+    name[name_len - 1] = 0;
+  }
+  if (total_mem) *total_mem = prop.totalGlobalMem;
+  if (num_cu) *num_cu = prop.multiProcessorCount;
+  return WF_OK;
+}
+
+int wf_malloc(void** d_ptr, size_t bytes)
+{
+  WF_REQUIRE(d_ptr != nullptr, "wf_malloc: null output");
+  *d_ptr = nullptr;
+  if (bytes == 0) return WF_OK;
+  WF_HIP_CHECK(hipMalloc(d_ptr, bytes));
+  return WF_OK;
+}
+int wf_free(void* d_ptr)
+{
+  if (d_ptr) WF_HIP_CHECK(hipFree(d_ptr));
+  return WF_OK;
+}
+int wf_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes)
+{
+  if (bytes) WF_HIP_CHECK(hipMemcpy(d_dst, h_src, bytes, hipMemcpyHostToDevice));
+  return WF_OK;
+}
+int wf_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes)
+{
+  if (bytes) WF_HIP_CHECK(hipMemcpy(h_dst, d_src, bytes, hipMemcpyDeviceToHost));
+  return WF_OK;
+}
+int wf_memset(void* d_dst, int value, size_t bytes, void* stream)
+{
+  if (bytes) WF_HIP_CHECK(hipMemsetAsync(d_dst, value, bytes, (hipStream_t)stream));
+  return WF_OK;
+}
+int wf_sync(void* stream)
+{
+  if (stream)
+    WF_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+  else
+    WF_HIP_CHECK(hipDeviceSynchronize());
+  return WF_OK;
+}
+
+// ---- geometry --------------------------------------------------------------
+int wf_geometry_hex(int P, int ncells, int nverts, const double* h_xverts, const int32_t* h_geom_dofmap,
+                    int use_fabs, int clamp, double* h_G, double* h_detJ)
+{
+  if (P < 1 || P > kMaxDegree) {
+    set_error("wf_geometry_hex: degree must be 1..7");
+    return WF_ERR_UNSUPPORTED;
+  }
+  WF_REQUIRE(ncells >= 0 && nverts >= 0 && h_xverts && h_geom_dofmap, "wf_geometry_hex: bad arguments");
+  for (size_t e = 0; e < (size_t)ncells * 8; ++e)
+    WF_REQUIRE(h_geom_dofmap[e] >= 0 && h_geom_dofmap[e] < nverts, "wf_geometry_hex: vertex index out of range");
+  const size_t nq = (size_t)(P + 1) * (P + 1) * (P + 1);
+  Scratch<double> d_x, d_pts, d_wts, d_G, d_det;
+  Scratch<int32_t> d_gd;
+  int rc;
+  if ((rc = dev_upload(&d_x.p, h_xverts, (size_t)nverts * 3, nullptr)) != WF_OK) return rc;
+  if ((rc = dev_upload(&d_gd.p, h_geom_dofmap, (size_t)ncells * 8, nullptr)) != WF_OK) return rc;
+  if ((rc = upload_tables(P, d_pts, d_wts)) != WF_OK) return rc;
+  if (h_G && (rc = dev_alloc(&d_G.p, (size_t)ncells * nq * 9, nullptr)) != WF_OK) return rc;
+  if (h_detJ && (rc = dev_alloc(&d_det.p, (size_t)ncells * nq, nullptr)) != WF_OK) return rc;
+  if ((rc = launch_geometry_hex(P, ncells, d_x.p, d_gd.p, d_pts.p, d_wts.p, use_fabs, clamp, d_G.p, nullptr,
+                                d_det.p, nullptr)) != WF_OK)
+    return rc;
+  WF_HIP_CHECK(hipDeviceSynchronize());
+  if (h_G) WF_HIP_CHECK(hipMemcpy(h_G, d_G.p, (size_t)ncells * nq * 9 * sizeof(double), hipMemcpyDeviceToHost));
+  if (h_detJ) WF_HIP_CHECK(hipMemcpy(h_detJ, d_det.p, (size_t)ncells * nq * sizeof(double), hipMemcpyDeviceToHost));
+  return WF_OK;
+}
+
+// ---- operators -------------------------------------------------------------
+int wf_op_create(const wf_op_desc* desc, wf_op** out)
+{
+  WF_REQUIRE(desc && out, "wf_op_create: null argument");
+  *out = nullptr;
+  const int P = desc->degree;
+  if (P < 1 || P > kMaxDegree) {
+    set_error("wf_op_create: degree must be 1..7 (hexahedron)");   // mass.hpp:91-92 "Not implemented"
+    return WF_ERR_UNSUPPORTED;
+  }
+  WF_REQUIRE(desc->kind == WF_OP_STIFFNESS || desc->kind == WF_OP_MASS_LUMPED || desc->kind == WF_OP_MASS_DENSE,
+             "wf_op_create: unknown operator kind");
+  WF_REQUIRE(desc->ncells >= 0 && desc->ndofs >= 0, "wf_op_create: negative size");
+  WF_REQUIRE(desc->h_dofmap || desc->ncells == 0, "wf_op_create: dofmap missing");
+  const int n = P + 1, nd = n * n * n;
+  const size_t ncells = (size_t)desc->ncells;
+  const bool have_mesh = desc->h_xverts && desc->h_geom_dofmap;
+
+  // host-side validation of every index the kernels will dereference
+  for (size_t e = 0; e < ncells * nd; ++e)
+    WF_REQUIRE(desc->h_dofmap[e] >= 0 && desc->h_dofmap[e] < desc->ndofs, "wf_op_create: dofmap entry out of range");
+  if (desc->h_perm) {
+    std::vector<char> seen(nd, 0);
+    for (int k = 0; k < nd; ++k) {
+      WF_REQUIRE(desc->h_perm[k] >= 0 && desc->h_perm[k] < nd && !seen[desc->h_perm[k]],
+                 "wf_op_create: perm is not a permutation");
+      seen[desc->h_perm[k]] = 1;
+    }
+  }
+  if (have_mesh)
+    for (size_t e = 0; e < ncells * 8; ++e)
+      WF_REQUIRE(desc->h_geom_dofmap[e] >= 0 && desc->h_geom_dofmap[e] < desc->nverts,
+                 "wf_op_create: vertex index out of range");
+
+  std::unique_ptr<wf_op, void (*)(wf_op*)> op(new wf_op, free_op);
+  op->kind = desc->kind;
+  op->P = P;
+  op->n = n;
+  op->nd = nd;
+  op->nq = nd;
+  op->ncells = desc->ncells;
+  op->ndofs = desc->ndofs;
+  op->coeff = -1.0 * desc->c0 * desc->c0;   // operators.hpp:115
+  int rc;
+
+  // tensor-ordered dofmap (permute.hpp:10-27 when the caller's element ordering differs)
+  {
+    std::vector<int32_t> tmp;
+    const int32_t* src = desc->h_dofmap;
+    if (desc->h_perm && ncells) {
+      tmp.resize(ncells * nd);
+      if ((rc = wf_reorder_dofmap(desc->ncells, nd, desc->h_perm, desc->h_dofmap, tmp.data())) != WF_OK) return rc;
+      src = tmp.data();
+    }
+    if ((rc = dev_upload(&op->d_dofmap, src, ncells * nd, &op->device_bytes)) != WF_OK) return rc;
+  }
+
+  std::vector<double> D(n * n);
+  gll_derivative_matrix(P, D.data());
+  for (int q = 0; q < n * n; ++q) op->dm.v[q] = D[q];
+  if ((rc = dev_upload(&op->d_D, D.data(), (size_t)n * n, &op->device_bytes)) != WF_OK) return rc;
+
+  const int use_fabs = (desc->flags & WF_FLAG_NO_FABS) ? 0 : 1;
+  const int clamp = (desc->flags & WF_FLAG_NO_CLAMP) ? 0 : 1;
+  Scratch<double> d_x, d_pts, d_wts;
+  Scratch<int32_t> d_gd;
+  if (have_mesh && ncells) {
+    if ((rc = dev_upload(&d_x.p, desc->h_xverts, (size_t)desc->nverts * 3, nullptr)) != WF_OK) return rc;
+    if ((rc = dev_upload(&d_gd.p, desc->h_geom_dofmap, ncells * 8, nullptr)) != WF_OK) return rc;
+    if ((rc = upload_tables(P, d_pts, d_wts)) != WF_OK) return rc;
+  }
+
+  if (desc->kind == WF_OP_STIFFNESS) {
+    const int CB = cells_per_batch(P);
+    const size_t nbatch = (ncells + CB - 1) / CB;
+    const size_t g6 = nbatch * CB * nd * 6;
+    if ((rc = dev_alloc(&op->d_G6blk, g6, &op->device_bytes)) != WF_OK) return rc;
+    if (g6) WF_HIP_CHECK(hipMemset(op->d_G6blk, 0, g6 * sizeof(double)));
+    if (desc->h_G) {
+      // reference layout G[ncells][nq][3][3] (precomputation.hpp:46) -> blocked upper triangle,
+      // staged in slabs to bound the temporary
+      const size_t slab_cells = std::max<size_t>(CB, (((size_t)64 << 20) / (nd * 9 * sizeof(double))) / CB * CB);
+      Scratch<double> d_G9;
+      if ((rc = dev_alloc(&d_G9.p, std::min(slab_cells, std::max<size_t>(ncells, 1)) * nd * 9, nullptr)) != WF_OK) return rc;
+      for (size_t c0 = 0; c0 < ncells; c0 += slab_cells) {
+        const size_t nc = std::min(slab_cells, ncells - c0);
+        WF_HIP_CHECK(hipMemcpy(d_G9.p, desc->h_G + c0 * nd * 9, nc * nd * 9 * sizeof(double), hipMemcpyHostToDevice));
+        // slabs start on a batch boundary, so the packed destination is offset by whole batches
+        if ((rc = launch_pack_G6(P, (int)nc, d_G9.p, op->d_G6blk + (c0 / CB) * CB * nd * 6, nullptr)) != WF_OK) return rc;
+        WF_HIP_CHECK(hipDeviceSynchronize());
+      }
+    } else if (have_mesh) {
+      if ((rc = launch_geometry_hex(P, desc->ncells, d_x.p, d_gd.p, d_pts.p, d_wts.p, use_fabs, clamp, nullptr,
+                                    op->d_G6blk, nullptr, nullptr)) != WF_OK)
+        return rc;
+    } else if (ncells) {
+      set_error("wf_op_create: stiffness needs h_G or the mesh (h_xverts, h_geom_dofmap)");
+      return WF_ERR_INVALID;
+    }
+  } else {
+    // mass operators: detJ[ncells][nq]
+    int nq1 = n;
+    if (desc->kind == WF_OP_MASS_DENSE) {
+      WF_REQUIRE(desc->h_phi1 && desc->nq1 >= 1 && desc->nq1 <= 16, "wf_op_create: dense mass needs phi1[nq1][P+1]");
+      WF_REQUIRE(desc->h_detJ, "wf_op_create: dense mass needs h_detJ[ncells][nq1^3]");
+      nq1 = desc->nq1;
+      if ((rc = dev_upload(&op->d_phi1, desc->h_phi1, (size_t)nq1 * n, &op->device_bytes)) != WF_OK) return rc;
+    }
+    op->nq1 = nq1;
+    op->nq = nq1 * nq1 * nq1;
+    if (desc->h_detJ) {
+      if ((rc = dev_upload(&op->d_detJ, desc->h_detJ, ncells * op->nq, &op->device_bytes)) != WF_OK) return rc;
+    } else if (have_mesh) {
+      if ((rc = dev_alloc(&op->d_detJ, ncells * nd, &op->device_bytes)) != WF_OK) return rc;
+      if ((rc = launch_geometry_hex(P, desc->ncells, d_x.p, d_gd.p, d_pts.p, d_wts.p, use_fabs, 0, nullptr, nullptr,
+                                    op->d_detJ, nullptr)) != WF_OK)
+        return rc;
+    } else if (ncells) {
+      set_error("wf_op_create: mass needs h_detJ or the mesh (h_xverts, h_geom_dofmap)");
+      return WF_ERR_INVALID;
+    }
+  }
+  WF_HIP_CHECK(hipDeviceSynchronize());
+  *out = op.release();
+  return WF_OK;
+}
+
+int wf_op_create_box(int kind, int degree, int nx, int ny, int nz, const double* h_xverts, double c0, int flags,
+                     wf_op** out)
+{
+  WF_REQUIRE(out != nullptr, "wf_op_create_box: null output");
+  *out = nullptr;
+  const int P = degree;
+  if (P < 1 || P > kMaxDegree) {
+    set_error("wf_op_create_box: degree must be 1..7 (hexahedron)");
+    return WF_ERR_UNSUPPORTED;
+  }
+  WF_REQUIRE(kind == WF_OP_STIFFNESS || kind == WF_OP_MASS_LUMPED, "wf_op_create_box: kind must be stiffness or lumped mass");
+  WF_REQUIRE(nx > 0 && ny > 0 && nz > 0 && h_xverts, "wf_op_create_box: bad mesh");
+  const size_t NX = (size_t)P * nx + 1, NY = (size_t)P * ny + 1, NZ = (size_t)P * nz + 1;
+  WF_REQUIRE(NX * NY * NZ < ((size_t)1 << 31), "wf_op_create_box: dof lattice exceeds int32");
+  const int n = P + 1, nd = n * n * n;
+
+  std::unique_ptr<wf_op, void (*)(wf_op*)> op(new wf_op, free_op);
+  op->kind = kind;
+  op->P = P;
+  op->n = n;
+  op->nd = nd;
+  op->nq = nd;
+  op->nq1 = n;
+  op->ncells = nx * ny * nz;
+  op->ndofs = (int)(NX * NY * NZ);
+  op->structured = 1;
+  op->nx = nx;
+  op->ny = ny;
+  op->nz = nz;
+  op->coeff = -1.0 * c0 * c0;
+  default_box_block(P, &op->bx, &op->by, &op->bz);
+  int rc;
+
+  std::vector<double> D(n * n);
+  gll_derivative_matrix(P, D.data());
+  for (int q = 0; q < n * n; ++q) op->dm.v[q] = D[q];
+  if ((rc = dev_upload(&op->d_D, D.data(), (size_t)n * n, &op->device_bytes)) != WF_OK) return rc;
+
+  Scratch<double> d_x, d_pts, d_wts;
+  const size_t nverts = (size_t)(nx + 1) * (ny + 1) * (nz + 1);
+  if ((rc = dev_upload(&d_x.p, h_xverts, nverts * 3, nullptr)) != WF_OK) return rc;
+  if ((rc = upload_tables(P, d_pts, d_wts)) != WF_OK) return rc;
+  const int use_fabs = (flags & WF_FLAG_NO_FABS) ? 0 : 1;
+  const int clamp = (flags & WF_FLAG_NO_CLAMP) ? 0 : 1;
+
+  if (kind == WF_OP_STIFFNESS) {
+    const size_t nblk = (size_t)((nx + op->bx - 1) / op->bx) * ((ny + op->by - 1) / op->by) * ((nz + op->bz - 1) / op->bz);
+    const size_t g6 = nblk * op->bx * op->by * op->bz * nd * 6;
+    if ((rc = dev_alloc(&op->d_G6blk, g6, &op->device_bytes)) != WF_OK) return rc;
+    WF_HIP_CHECK(hipMemset(op->d_G6blk, 0, g6 * sizeof(double)));
+    if ((rc = launch_geometry_box(P, nx, ny, nz, op->bx, op->by, op->bz, d_x.p, d_pts.p, d_wts.p, use_fabs, clamp,
+                                  op->d_G6blk, nullptr, nullptr)) != WF_OK)
+      return rc;
+  } else {
+    // pre-assembled lumped mass diagonal: y += m .* x is 24 B/dof instead of the
+    // 34.8 B/dof gather/transform/scatter of spectral_mass.hpp:84-89
+    if ((rc = dev_alloc(&op->d_mdiag, (size_t)op->ndofs, &op->device_bytes)) != WF_OK) return rc;
+    WF_HIP_CHECK(hipMemset(op->d_mdiag, 0, (size_t)op->ndofs * sizeof(double)));
+    if ((rc = launch_geometry_box(P, nx, ny, nz, 1, 1, 1, d_x.p, d_pts.p, d_wts.p, use_fabs, clamp, nullptr,
+                                  op->d_mdiag, nullptr)) != WF_OK)
+      return rc;
+  }
+  WF_HIP_CHECK(hipDeviceSynchronize());
+  *out = op.release();
+  return WF_OK;
+}
+
+int wf_op_apply(wf_op* op, const double* d_x, double* d_y, void* stream)
+{
+  WF_REQUIRE(op && d_x && d_y, "wf_op_apply: null argument");
+  hipStream_t s = (hipStream_t)stream;
+  if (op->structured) {
+    if (op->kind == WF_OP_STIFFNESS)
+      return launch_stiffness_box(op->P, op->nx, op->ny, op->nz, op->bx, op->by, op->bz, op->d_G6blk, op->d_D, op->dm,
+                                  op->coeff, d_x, d_y, s);
+    return wf_pointwise_mult_add(op->ndofs, op->d_mdiag, d_x, d_y, stream);
+  }
+  switch (op->kind) {
+    case WF_OP_STIFFNESS:
+      return launch_stiffness_generic(op->P, op->ncells, op->d_dofmap, op->d_G6blk, op->d_D, op->dm, op->coeff, d_x,
+                                      d_y, s);
+    case WF_OP_MASS_LUMPED:
+      return launch_mass_lumped((int64_t)op->ncells * op->nd, op->d_dofmap, op->d_detJ, d_x, d_y, s);
+    case WF_OP_MASS_DENSE:
+      return launch_mass_dense(op->P, op->nq1, op->ncells, op->d_dofmap, op->d_phi1, op->d_detJ, d_x, d_y, s);
+  }
+  set_error("wf_op_apply: corrupt handle");
+  return WF_ERR_INVALID;
+}
+
+int wf_op_info(const wf_op* op, wf_op_info_t* info)
+{
+  WF_REQUIRE(op && info, "wf_op_info: null argument");
+  info->kind = op->kind;
+  info->degree = op->P;
+  info->num_cells = op->ncells;
+  info->num_dofs_cell = op->nd;
+  info->num_quads = op->nq;
+  info->ndofs = op->ndofs;
+  info->structured = op->structured;
+  info->flops = 4.0 * op->ncells * (double)op->nq * op->nd;   // mass.hpp:71
+  if (op->kind == WF_OP_STIFFNESS)
+    info->alg_bytes = (double)op->ncells * (48.0 * op->nq + 4.0 * op->nd) + 16.0 * op->ndofs;
+  else if (op->structured)
+    info->alg_bytes = 24.0 * op->ndofs;
+  else
+    info->alg_bytes = (double)op->ncells * (8.0 * op->nq + 4.0 * op->nd) + 16.0 * op->ndofs;
+  info->device_bytes = op->device_bytes;
+  return WF_OK;
+}
+
+int wf_op_destroy(wf_op* op)
+{
+  free_op(op);
+  return WF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,68 @@
+// Internal declarations shared by the libwavehip translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "wavehip.h"
+
+namespace wf {
+
+constexpr int kMaxDegree = 7;
+constexpr int kMaxN = kMaxDegree + 1;
+
+void set_error(const std::string& msg);
+
+#define WF_HIP_CHECK(expr)                                                          \
+  do {                                                                              \
+    hipError_t _e = (expr);                                                         \
+    if (_e != hipSuccess) {                                                         \
+      ::wf::set_error(std::string(#expr) + " failed: " + hipGetErrorString(_e));     \
+      return WF_ERR_HIP;                                                            \
+    }                                                                               \
+  } while (0)
+
+#define WF_REQUIRE(cond, msg)                    \
+  do {                                           \
+    if (!(cond)) {                               \
+      ::wf::set_error(msg);                      \
+      return WF_ERR_INVALID;                     \
+    }                                            \
+  } while (0)
+
+// 1-D collocation derivative matrix, passed by value as a kernel argument so
+// that compile-time-indexed entries become scalar (SGPR) operands.
+struct DMat {
+  double v[kMaxN * kMaxN];
+};
+
+// ---- host tabulation (tables.cpp) ----
+void gll_points_weights(int n, double* pts, double* wts);
+void gll_derivative_matrix(int P, double* D);  // clamped, D[q*n + a]
+
+// cells per workgroup batch of the column-thread kernels: floor(256 / n^2)
+inline int cells_per_batch(int P) { return 256 / ((P + 1) * (P + 1)); }
+
+// ---- kernel launchers (kernels.hip) ----
+int launch_geometry_hex(int P, int ncells, const double* d_xverts, const int32_t* d_geom_dofmap,
+                        const double* d_pts, const double* d_wts, int use_fabs, int clamp,
+                        double* d_G9, double* d_G6blk, double* d_detJ, hipStream_t s);
+int launch_geometry_box(int P, int nx, int ny, int nz, int bx, int by, int bz, const double* d_xverts,
+                        const double* d_pts, const double* d_wts, int use_fabs, int clamp,
+                        double* d_G6blk, double* d_detJ_lattice, hipStream_t s);
+int launch_pack_G6(int P, int ncells, const double* d_G9, double* d_G6blk, hipStream_t s);
+int launch_stiffness_generic(int P, int ncells, const int32_t* d_dofmap, const double* d_G6blk,
+                             const double* d_D, const DMat& dm, double coeff, const double* d_x,
+                             double* d_y, hipStream_t s);
+int launch_stiffness_box(int P, int nx, int ny, int nz, int bx, int by, int bz, const double* d_G6blk,
+                         const double* d_D, const DMat& dm, double coeff, const double* d_x, double* d_y,
+                         hipStream_t s);
+int launch_mass_lumped(int64_t nentries, const int32_t* d_dofmap, const double* d_detJ, const double* d_x,
+                       double* d_y, hipStream_t s);
+int launch_mass_dense(int P, int nq1, int ncells, const int32_t* d_dofmap, const double* d_phi1,
+                      const double* d_detJ, const double* d_x, double* d_y, hipStream_t s);
+
+}  // namespace wf

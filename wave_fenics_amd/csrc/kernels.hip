@@ -1,0 +1,676 @@
+// libwavehip device kernels (gfx950 / MI355X only).
+//
+// Hot path: the sum-factorised hexahedral stiffness operator
+//     y += -c0^2 * sum_cells  P_c^T  D^T (G .* (D P_c x))
+// replacing the dense per-cell loop of common/operators.hpp:113-133 (skernel)
+// and the gather/kernel/scatter launch triple of common/cuda/mass.hpp:76-95.
+//
+// Thread mapping ("column threads", 64-wide waves): one thread owns the column
+// (i, j, *) of one cell and keeps its n = P+1 values along z in registers; a
+// 256-thread workgroup processes CB = floor(256 / n^2) cells at once (P4: 10
+// cells, 250 of 256 lanes busy).  x- and y-direction contractions go through an
+// LDS tile of the cell's dofs, the z-direction contraction stays in registers.
+// The per-point symmetric geometry tensor (6 doubles) is the dominant HBM
+// stream; it is stored pre-blocked per workgroup so that every lane issues
+// 16-byte loads that are contiguous across the wave, and all loads of a batch
+// are issued before any arithmetic.
+#include "common.h"
+
+namespace wf {
+
+// --------------------------------------------------------------------------
+// small helpers
+// --------------------------------------------------------------------------
+__device__ __forceinline__ double clamp101(double v)
+{
+  // xt::isclose(v, b) with rtol 1e-5, atol 1e-8, applied for b = -1, 0, 1
+  // (common/precomputation.hpp:105-107)
+  if (fabs(v + 1.0) <= 1e-8 + 1e-5) v = -1.0;
+  if (fabs(v) <= 1e-8) v = 0.0;
+  if (fabs(v - 1.0) <= 1e-8 + 1e-5) v = 1.0;
+  return v;
+}
+
+__device__ __forceinline__ double det3(const double* A)
+{
+  return A[0] * (A[4] * A[8] - A[5] * A[7]) - A[1] * (A[3] * A[8] - A[5] * A[6])
+         + A[2] * (A[3] * A[7] - A[4] * A[6]);
+}
+
+// Jacobian, |det J| w and G = (J^-1 detJ) J^-T at one point of a trilinear
+// hexahedron (common/precomputation.hpp:83-100).  xv: the cell's 8 vertices
+// [v][3], vertex v = a + 2b + 4c; X: reference point.
+__device__ __forceinline__ void hex_point_geometry(const double (*xv)[3], double X0, double X1, double X2,
+                                                   double w, int use_fabs, int do_clamp, double* G9,
+                                                   double* detJw)
+{
+  double J[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) J[i] = 0.0;
+  const double f0[2] = {1.0 - X0, X0}, f1[2] = {1.0 - X1, X1}, f2[2] = {1.0 - X2, X2};
+  const double g[2] = {-1.0, 1.0};
+#pragma unroll
+  for (int v = 0; v < 8; ++v) {
+    const int a = v & 1, b = (v >> 1) & 1, c = (v >> 2) & 1;
+    // the reference clamps the tabulated cmap derivatives to -1/0/1
+    // (precomputation.hpp:56-58)
+    double d0 = g[a] * f1[b] * f2[c];
+    double d1 = f0[a] * g[b] * f2[c];
+    double d2 = f0[a] * f1[b] * g[c];
+    if (do_clamp) {
+      d0 = clamp101(d0);
+      d1 = clamp101(d1);
+      d2 = clamp101(d2);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      J[i * 3 + 0] += xv[v][i] * d0;
+      J[i * 3 + 1] += xv[v][i] * d1;
+      J[i * 3 + 2] += xv[v][i] * d2;
+    }
+  }
+  double d = det3(J);
+  const double idet = 1.0 / d;
+  if (use_fabs) d = fabs(d);
+  d *= w;
+  *detJw = d;
+  if (G9) {
+    double Ji[9];
+    Ji[0] = (J[4] * J[8] - J[5] * J[7]) * idet;
+    Ji[1] = (J[2] * J[7] - J[1] * J[8]) * idet;
+    Ji[2] = (J[1] * J[5] - J[2] * J[4]) * idet;
+    Ji[3] = (J[5] * J[6] - J[3] * J[8]) * idet;
+    Ji[4] = (J[0] * J[8] - J[2] * J[6]) * idet;
+    Ji[5] = (J[2] * J[3] - J[0] * J[5]) * idet;
+    Ji[6] = (J[3] * J[7] - J[4] * J[6]) * idet;
+    Ji[7] = (J[1] * J[6] - J[0] * J[7]) * idet;
+    Ji[8] = (J[0] * J[4] - J[1] * J[3]) * idet;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) s += (Ji[i * 3 + k] * d) * Ji[j * 3 + k];
+        G9[i * 3 + j] = do_clamp ? clamp101(s) : s;
+      }
+  }
+}
+
+// Blocked symmetric geometry layout shared by the stiffness kernels:
+//   G6blk[batch][k][p][t][e],  t = cl * n^2 + (j * n + i) < NT = CB * n^2,
+//   (p, e) -> component: (0,0)=G00 (0,1)=G01 (1,0)=G02 (1,1)=G11 (2,0)=G12 (2,1)=G22
+__device__ __forceinline__ size_t g6_index(int n, int NT, size_t batch, int k, int p, int t, int e)
+{
+  return ((((batch * n + k) * 3 + p) * (size_t)NT + t) * 2) + e;
+}
+
+__device__ __forceinline__ void store_g6(double* G6blk, int n, int NT, size_t batch, int k, int t,
+                                         const double* G9)
+{
+  G6blk[g6_index(n, NT, batch, k, 0, t, 0)] = G9[0];
+  G6blk[g6_index(n, NT, batch, k, 0, t, 1)] = G9[1];
+  G6blk[g6_index(n, NT, batch, k, 1, t, 0)] = G9[2];
+  G6blk[g6_index(n, NT, batch, k, 1, t, 1)] = G9[4];
+  G6blk[g6_index(n, NT, batch, k, 2, t, 0)] = G9[5];
+  G6blk[g6_index(n, NT, batch, k, 2, t, 1)] = G9[8];
+}
+
+// --------------------------------------------------------------------------
+// geometry kernels (setup; a2/a13)
+// --------------------------------------------------------------------------
+__global__ void k_geometry_hex(int n, int CB, int ncells, const double* __restrict__ xverts,
+                               const int32_t* __restrict__ geom_dofmap, const double* __restrict__ pts,
+                               const double* __restrict__ wts, int use_fabs, int do_clamp,
+                               double* __restrict__ G9out, double* __restrict__ G6blk,
+                               double* __restrict__ detJ)
+{
+  const int nd = n * n * n;
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (size_t)ncells * nd) return;
+  const int c = (int)(gid / nd), q = (int)(gid % nd);
+  const int i = q % n, j = (q / n) % n, k = q / (n * n);
+  double xv[8][3];
+  for (int v = 0; v < 8; ++v) {
+    const int32_t vi = geom_dofmap[(size_t)c * 8 + v];
+    xv[v][0] = xverts[(size_t)vi * 3 + 0];
+    xv[v][1] = xverts[(size_t)vi * 3 + 1];
+    xv[v][2] = xverts[(size_t)vi * 3 + 2];
+  }
+  double G9[9], d;
+  const bool wantG = (G9out != nullptr) || (G6blk != nullptr);
+  hex_point_geometry(xv, pts[i], pts[j], pts[k], wts[i] * wts[j] * wts[k], use_fabs, do_clamp,
+                     wantG ? G9 : nullptr, &d);
+  if (detJ) detJ[gid] = d;
+  if (G9out)
+    for (int m = 0; m < 9; ++m) G9out[gid * 9 + m] = G9[m];
+  if (G6blk) {
+    const int NT = CB * n * n;
+    store_g6(G6blk, n, NT, c / CB, k, (c % CB) * n * n + j * n + i, G9);
+  }
+}
+
+// reference-layout G[ncells][nq][3][3] -> blocked symmetric layout (upper triangle)
+__global__ void k_pack_G6(int n, int CB, int ncells, const double* __restrict__ G9in,
+                          double* __restrict__ G6blk)
+{
+  const int nd = n * n * n;
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (size_t)ncells * nd) return;
+  const int c = (int)(gid / nd), q = (int)(gid % nd);
+  const int i = q % n, j = (q / n) % n, k = q / (n * n);
+  double G9[9];
+  for (int m = 0; m < 9; ++m) G9[m] = G9in[gid * 9 + m];
+  store_g6(G6blk, n, CB * n * n, c / CB, k, (c % CB) * n * n + j * n + i, G9);
+}
+
+// Structured box: one thread per (cell, point); the cell's vertices come from the
+// vertex lattice.  Writes the blocked G of the box stiffness kernel (block =
+// bx*by*bz cells, padded blocks stay zero) and/or accumulates the lumped mass
+// diagonal m[g] += |det J| w on the dof lattice.
+__global__ void k_geometry_box(int n, int nx, int ny, int nz, int bx, int by, int bz,
+                               const double* __restrict__ xverts, const double* __restrict__ pts,
+                               const double* __restrict__ wts, int use_fabs, int do_clamp,
+                               double* __restrict__ G6blk, double* __restrict__ mdiag)
+{
+  const int P = n - 1, nd = n * n * n;
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t ncells = (size_t)nx * ny * nz;
+  if (gid >= ncells * nd) return;
+  const int c = (int)(gid / nd), q = (int)(gid % nd);
+  const int i = q % n, j = (q / n) % n, k = q / (n * n);
+  const int cx = c % nx, cy = (c / nx) % ny, cz = c / (nx * ny);
+  double xv[8][3];
+  for (int v = 0; v < 8; ++v) {
+    const size_t vi = (size_t)(cx + (v & 1)) + (size_t)(nx + 1) * ((cy + ((v >> 1) & 1)) + (size_t)(ny + 1) * (cz + ((v >> 2) & 1)));
+    xv[v][0] = xverts[vi * 3 + 0];
+    xv[v][1] = xverts[vi * 3 + 1];
+    xv[v][2] = xverts[vi * 3 + 2];
+  }
+  double G9[9], d;
+  hex_point_geometry(xv, pts[i], pts[j], pts[k], wts[i] * wts[j] * wts[k], use_fabs, do_clamp,
+                     G6blk ? G9 : nullptr, &d);
+  if (mdiag) {
+    const size_t NX = (size_t)P * nx + 1, NY = (size_t)P * ny + 1;
+    const size_t g = (size_t)(P * cx + i) + NX * ((size_t)(P * cy + j) + NY * (size_t)(P * cz + k));
+    unsafeAtomicAdd(&mdiag[g], d);
+  }
+  if (G6blk) {
+    const int nbx = (nx + bx - 1) / bx, nby = (ny + by - 1) / by;
+    const int Bx = cx / bx, By = cy / by, Bz = cz / bz;
+    const size_t blk = (size_t)Bx + (size_t)nbx * (By + (size_t)nby * Bz);
+    const int cl = (cx % bx) + bx * ((cy % by) + by * (cz % bz));
+    const int CB = bx * by * bz;
+    store_g6(G6blk, n, CB * n * n, blk, k, cl * n * n + j * n + i, G9);
+  }
+}
+
+// --------------------------------------------------------------------------
+// stiffness: per-thread core shared by the generic and the box kernel
+// --------------------------------------------------------------------------
+// U: LDS dofs of this thread's cell, addressed U[k*sk + j*sj + i] (strides in
+// doubles; the generic kernel uses the compact cell layout sk = n^2, sj = n,
+// the box kernel addresses the cell inside the block's dof tile).
+// Fr, Fs: LDS scratch of the cell, compact layout.  sD: LDS copy of D.
+// Output: out[k] = (K_cell u)[i, j, k].  Two workgroup barriers inside.
+template <int P>
+__device__ __forceinline__ void stiffness_column(const double* __restrict__ U, int sk, int sj,
+                                                 double* __restrict__ Fr, double* __restrict__ Fs,
+                                                 const double* __restrict__ sD, const DMat& dm,
+                                                 const double2 (&g)[P + 1][3], double coeff, int i,
+                                                 int j, bool active, double (&out)[P + 1])
+{
+  constexpr int n = P + 1, n2 = n * n;
+  double ft[n];
+  if (active) {
+    double ru[n];
+#pragma unroll
+    for (int k = 0; k < n; ++k) ru[k] = U[k * sk + j * sj + i];
+    double di[n], dj[n];
+#pragma unroll
+    for (int a = 0; a < n; ++a) {
+      di[a] = sD[i * n + a];
+      dj[a] = sD[j * n + a];
+    }
+#pragma unroll
+    for (int k = 0; k < n; ++k) {
+      double ur = 0.0, us = 0.0, ut = 0.0;
+#pragma unroll
+      for (int a = 0; a < n; ++a) {
+        ur += di[a] * U[k * sk + j * sj + a];
+        us += dj[a] * U[k * sk + a * sj + i];
+        ut += dm.v[k * n + a] * ru[a];
+      }
+      const double g00 = g[k][0].x, g01 = g[k][0].y, g02 = g[k][1].x, g11 = g[k][1].y,
+                   g12 = g[k][2].x, g22 = g[k][2].y;
+      // operators.hpp:126-128: fw = coeff * (G row . w)
+      const double fr = coeff * (g00 * ur + g01 * us + g02 * ut);
+      const double fs = coeff * (g01 * ur + g11 * us + g12 * ut);
+      ft[k] = coeff * (g02 * ur + g12 * us + g22 * ut);
+      Fr[k * n2 + j * n + i] = fr;
+      Fs[k * n2 + j * n + i] = fs;
+    }
+  }
+  __syncthreads();
+  if (active) {
+    double dti[n], dtj[n];
+#pragma unroll
+    for (int a = 0; a < n; ++a) {
+      dti[a] = sD[a * n + i];
+      dtj[a] = sD[a * n + j];
+    }
+#pragma unroll
+    for (int k = 0; k < n; ++k) {
+      double s = 0.0;
+#pragma unroll
+      for (int a = 0; a < n; ++a) {
+        s += dti[a] * Fr[k * n2 + j * n + a];
+        s += dtj[a] * Fs[k * n2 + a * n + i];
+        s += dm.v[a * n + k] * ft[a];
+      }
+      out[k] = s;
+    }
+  }
+}
+
+// --------------------------------------------------------------------------
+// generic stiffness: arbitrary tensor-ordered dofmap, atomic scatter
+// --------------------------------------------------------------------------
+template <int P>
+__global__ __launch_bounds__(256) void k_stiffness_generic(int ncells, const int32_t* __restrict__ dofmap,
+                                                           const double2* __restrict__ G6blk,
+                                                           const double* __restrict__ dD, DMat dm,
+                                                           double coeff, const double* __restrict__ x,
+                                                           double* __restrict__ y)
+{
+  constexpr int n = P + 1, n2 = n * n, nd = n * n2;
+  constexpr int CB = 256 / n2, NT = CB * n2;
+  constexpr int NFLAT = (CB * nd + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* U = smem;                 // [CB][nd]
+  double* Fr = U + CB * nd;         // [CB][nd]
+  double* Fs = Fr + CB * nd;        // [CB][nd]
+  double* sD = Fs + CB * nd;        // [n][n]
+
+  const int t = threadIdx.x;
+  const size_t batch = blockIdx.x;
+  const int cell0 = (int)batch * CB;
+  const bool active = t < NT;
+  const int cl = t / n2, ji = t % n2, j = ji / n, i = ji % n;
+
+  // 1. issue the whole geometry stream of this batch first (16 B per lane,
+  //    contiguous across the wave); padded cells read zeros.
+  double2 g[n][3];
+  if (active) {
+    const double2* gp = G6blk + (batch * n * 3) * (size_t)NT + t;
+#pragma unroll
+    for (int k = 0; k < n; ++k)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) g[k][p] = gp[(size_t)(k * 3 + p) * NT];
+  }
+  if (t < n * n) sD[t] = dD[t];
+
+  // 2. gather: flat, coalesced dofmap reads; indices stay in registers for the scatter
+  int32_t idx[NFLAT];
+  const int nvalid = min(CB, ncells - cell0) * nd;
+#pragma unroll
+  for (int m = 0; m < NFLAT; ++m) {
+    const int pos = t + 256 * m;
+    idx[m] = -1;
+    if (pos < nvalid) {
+      idx[m] = dofmap[(size_t)cell0 * nd + pos];
+      U[pos] = x[idx[m]];
+    } else if (pos < CB * nd) {
+      U[pos] = 0.0;
+    }
+  }
+  __syncthreads();
+
+  double out[n];
+  stiffness_column<P>(U + cl * nd, n2, n, Fr + cl * nd, Fs + cl * nd, sD, dm, g, coeff, i, j, active, out);
+
+  // 3. element results back through LDS (Fr is free after the second barrier
+  //    only for this thread's own entries -> use U, whose reads all precede the
+  //    first barrier inside stiffness_column), then flat atomic scatter-add.
+  if (active) {
+#pragma unroll
+    for (int k = 0; k < n; ++k) U[cl * nd + k * n2 + ji] = out[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int m = 0; m < NFLAT; ++m) {
+    const int pos = t + 256 * m;
+    if (idx[m] >= 0) unsafeAtomicAdd(&y[idx[m]], U[pos]);
+  }
+}
+
+// --------------------------------------------------------------------------
+// structured box stiffness: implicit dofmap, block dof tile in LDS, atomics only
+// on dofs shared with a neighbouring block
+// --------------------------------------------------------------------------
+template <int P>
+__global__ __launch_bounds__(256) void k_stiffness_box(int nx, int ny, int nz, int bx, int by, int bz,
+                                                       const double2* __restrict__ G6blk,
+                                                       const double* __restrict__ dD, DMat dm,
+                                                       double coeff, const double* __restrict__ x,
+                                                       double* __restrict__ y)
+{
+  constexpr int n = P + 1, n2 = n * n, nd = n * n2;
+  const int CB = bx * by * bz, NT = CB * n2;
+  const int TX = P * bx + 1, TY = P * by + 1, TZ = P * bz + 1;
+  const int tile = TX * TY * TZ;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* Ut = smem;                         // [TZ][TY][TX] x tile, later the y tile
+  double* Fr = Ut + ((tile + 1) & ~1);       // [CB][nd]
+  double* Fs = Fr + CB * nd;                 // [CB][nd]
+  double* sD = Fs + CB * nd;                 // [n][n]
+
+  const int t = threadIdx.x;
+  const int nbx = (nx + bx - 1) / bx, nby = (ny + by - 1) / by;
+  const int Bx = blockIdx.x % nbx, By = (blockIdx.x / nbx) % nby, Bz = blockIdx.x / (nbx * nby);
+  const bool inrange = t < NT;
+  const int cl = t / n2, ji = t % n2, j = ji / n, i = ji % n;
+  const int lx = cl % bx, ly = (cl / bx) % by, lz = cl / (bx * by);
+  const int cx = Bx * bx + lx, cy = By * by + ly, cz = Bz * bz + lz;
+  const bool active = inrange && cx < nx && cy < ny && cz < nz;
+
+  double2 g[n][3];
+  if (inrange) {
+    const double2* gp = G6blk + ((size_t)blockIdx.x * n * 3) * (size_t)NT + t;
+#pragma unroll
+    for (int k = 0; k < n; ++k)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) g[k][p] = gp[(size_t)(k * 3 + p) * NT];
+  }
+  if (t < n * n) sD[t] = dD[t];
+
+  // dof tile of this block inside the global lattice (clipped at the mesh end)
+  const int NX = P * nx + 1, NY = P * ny + 1, NZ = P * nz + 1;
+  const int I0 = P * Bx * bx, J0 = P * By * by, K0 = P * Bz * bz;
+  const int EX = min(TX, NX - I0), EY = min(TY, NY - J0), EZ = min(TZ, NZ - K0);
+  for (int pos = t; pos < tile; pos += 256) {
+    const int I = pos % TX, J = (pos / TX) % TY, K = pos / (TX * TY);
+    double v = 0.0;
+    if (I < EX && J < EY && K < EZ)
+      v = x[(size_t)(I0 + I) + (size_t)NX * ((size_t)(J0 + J) + (size_t)NY * (K0 + K))];
+    Ut[pos] = v;
+  }
+  __syncthreads();
+
+  double out[n];
+  const double* Uc = Ut + (P * lz) * TX * TY + (P * ly) * TX + P * lx;
+  stiffness_column<P>(Uc, TX * TY, TX, Fr + cl * nd, Fs + cl * nd, sD, dm, g, coeff, i, j, active, out);
+
+  // y tile: zero, accumulate the cells of the block with LDS atomics
+  __syncthreads();
+  for (int pos = t; pos < tile; pos += 256) Ut[pos] = 0.0;
+  __syncthreads();
+  if (active) {
+    double* Yc = Ut + (P * lz) * TX * TY + (P * ly) * TX + P * lx;
+#pragma unroll
+    for (int k = 0; k < n; ++k) atomicAdd(&Yc[k * TX * TY + j * TX + i], out[k]);
+  }
+  __syncthreads();
+  // flush: dofs interior to the block (or on the mesh boundary) are exclusive to
+  // this workgroup -> plain read-modify-write; faces shared with a neighbouring
+  // block -> global atomic add.
+  const bool sx0 = Bx > 0, sy0 = By > 0, sz0 = Bz > 0;
+  const bool sx1 = I0 + TX < NX, sy1 = J0 + TY < NY, sz1 = K0 + TZ < NZ;
+  for (int pos = t; pos < tile; pos += 256) {
+    const int I = pos % TX, J = (pos / TX) % TY, K = pos / (TX * TY);
+    if (I < EX && J < EY && K < EZ) {
+      const size_t gidx = (size_t)(I0 + I) + (size_t)NX * ((size_t)(J0 + J) + (size_t)NY * (K0 + K));
+      const bool shared = (sx0 && I == 0) || (sx1 && I == TX - 1) || (sy0 && J == 0) || (sy1 && J == TY - 1)
+                          || (sz0 && K == 0) || (sz1 && K == TZ - 1);
+      const double v = Ut[pos];
+      if (shared)
+        unsafeAtomicAdd(&y[gidx], v);
+      else
+        y[gidx] += v;
+    }
+  }
+}
+
+// --------------------------------------------------------------------------
+// lumped (spectral) mass: fused gather * detJ -> scatter-add
+// replaces the three launches of common/cuda/spectral_mass.hpp:84-89
+// --------------------------------------------------------------------------
+__global__ void k_mass_lumped(int64_t nentries, const int32_t* __restrict__ dofmap,
+                              const double* __restrict__ detJ, const double* __restrict__ x,
+                              double* __restrict__ y)
+{
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < nentries) {
+    const int32_t d = dofmap[e];
+    unsafeAtomicAdd(&y[d], x[d] * detJ[e]);
+  }
+}
+
+// --------------------------------------------------------------------------
+// dense mass Phi^T D Phi with a tensor-product rule, sum-factorised:
+// replaces common/cuda/mass_kernel.cu:5-46 and the DGEMM pair of
+// demo/gpu_operator/main.cpp:149-155.  One workgroup per cell; the tall-skinny
+// (k >> m ~ n) basis products become three 1-D contractions through LDS.
+// phi1: [nq1][n] row-major.
+// --------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_mass_dense(int n, int m, int ncells,
+                                                    const int32_t* __restrict__ dofmap,
+                                                    const double* __restrict__ phi1,
+                                                    const double* __restrict__ detJ,
+                                                    const double* __restrict__ x, double* __restrict__ y)
+{
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int mx = max(n, m);
+  double* A = smem;                       // ping  [mx^3]
+  double* B = A + mx * mx * mx;           // pong  [mx^3]
+  double* sphi = B + mx * mx * mx;        // [m][n]
+  const int t = threadIdx.x;
+  const int nd = n * n * n, nq = m * m * m;
+  for (int p = t; p < m * n; p += 256) sphi[p] = phi1[p];
+  for (int c = blockIdx.x; c < ncells; c += gridDim.x) {
+    __syncthreads();
+    for (int p = t; p < nd; p += 256) A[p] = x[dofmap[(size_t)c * nd + p]];
+    __syncthreads();
+    // forward: u[k][j][i] -> q index, one direction at a time
+    // x: B[k][j][qi] = sum_i phi[qi][i] A[k][j][i]     (n*n*m)
+    for (int p = t; p < n * n * m; p += 256) {
+      const int qi = p % m, kj = p / m;
+      double s = 0.0;
+      for (int a = 0; a < n; ++a) s += sphi[qi * n + a] * A[kj * n + a];
+      B[p] = s;
+    }
+    __syncthreads();
+    // y: A[k][qj][qi] = sum_j phi[qj][j] B[k][j][qi]   (n*m*m)
+    for (int p = t; p < n * m * m; p += 256) {
+      const int qi = p % m, qj = (p / m) % m, k = p / (m * m);
+      double s = 0.0;
+      for (int a = 0; a < n; ++a) s += sphi[qj * n + a] * B[(k * n + a) * m + qi];
+      A[p] = s;
+    }
+    __syncthreads();
+    // z + D: B[qk][qj][qi] = detJ * sum_k phi[qk][k] A[k][qj][qi]   (m^3)
+    for (int p = t; p < nq; p += 256) {
+      const int qji = p % (m * m), qk = p / (m * m);
+      double s = 0.0;
+      for (int a = 0; a < n; ++a) s += sphi[qk * n + a] * A[a * m * m + qji];
+      B[p] = s * detJ[(size_t)c * nq + p];
+    }
+    __syncthreads();
+    // backward z: A[k][qj][qi] = sum_qk phi[qk][k] B[qk][qj][qi]
+    for (int p = t; p < n * m * m; p += 256) {
+      const int qji = p % (m * m), k = p / (m * m);
+      double s = 0.0;
+      for (int a = 0; a < m; ++a) s += sphi[a * n + k] * B[a * m * m + qji];
+      A[p] = s;
+    }
+    __syncthreads();
+    // backward y: B[k][j][qi] = sum_qj phi[qj][j] A[k][qj][qi]
+    for (int p = t; p < n * n * m; p += 256) {
+      const int qi = p % m, j = (p / m) % n, k = p / (m * n);
+      double s = 0.0;
+      for (int a = 0; a < m; ++a) s += sphi[a * n + j] * A[(k * m + a) * m + qi];
+      B[p] = s;
+    }
+    __syncthreads();
+    // backward x + scatter: y[dof] += sum_qi phi[qi][i] B[k][j][qi]
+    for (int p = t; p < nd; p += 256) {
+      const int i = p % n, kj = p / n;
+      double s = 0.0;
+      for (int a = 0; a < m; ++a) s += sphi[a * n + i] * B[kj * m + a];
+      unsafeAtomicAdd(&y[dofmap[(size_t)c * nd + p]], s);
+    }
+  }
+}
+
+// --------------------------------------------------------------------------
+// launchers
+// --------------------------------------------------------------------------
+static inline unsigned grid_for(size_t n, unsigned block) { return (unsigned)((n + block - 1) / block); }
+
+#define WF_LAUNCH_CHECK()                                                       \
+  do {                                                                          \
+    hipError_t _e = hipGetLastError();                                          \
+    if (_e != hipSuccess) {                                                     \
+      set_error(std::string("kernel launch failed: ") + hipGetErrorString(_e)); \
+      return WF_ERR_HIP;                                                        \
+    }                                                                           \
+  } while (0)
+
+int launch_geometry_hex(int P, int ncells, const double* d_xverts, const int32_t* d_geom_dofmap,
+                        const double* d_pts, const double* d_wts, int use_fabs, int clamp, double* d_G9,
+                        double* d_G6blk, double* d_detJ, hipStream_t s)
+{
+  const int n = P + 1;
+  const size_t N = (size_t)ncells * n * n * n;
+  if (N == 0) return WF_OK;
+  hipLaunchKernelGGL(k_geometry_hex, dim3(grid_for(N, 256)), dim3(256), 0, s, n, cells_per_batch(P), ncells,
+                     d_xverts, d_geom_dofmap, d_pts, d_wts, use_fabs, clamp, d_G9, d_G6blk, d_detJ);
+  WF_LAUNCH_CHECK();
+  return WF_OK;
+}
+
+int launch_pack_G6(int P, int ncells, const double* d_G9, double* d_G6blk, hipStream_t s)
+{
+  const int n = P + 1;
+  const size_t N = (size_t)ncells * n * n * n;
+  if (N == 0) return WF_OK;
+  hipLaunchKernelGGL(k_pack_G6, dim3(grid_for(N, 256)), dim3(256), 0, s, n, cells_per_batch(P), ncells, d_G9,
+                     d_G6blk);
+  WF_LAUNCH_CHECK();
+  return WF_OK;
+}
+
+int launch_geometry_box(int P, int nx, int ny, int nz, int bx, int by, int bz, const double* d_xverts,
+                        const double* d_pts, const double* d_wts, int use_fabs, int clamp, double* d_G6blk,
+                        double* d_mdiag, hipStream_t s)
+{
+  const int n = P + 1;
+  const size_t N = (size_t)nx * ny * nz * n * n * n;
+  if (N == 0) return WF_OK;
+  hipLaunchKernelGGL(k_geometry_box, dim3(grid_for(N, 256)), dim3(256), 0, s, n, nx, ny, nz, bx, by, bz,
+                     d_xverts, d_pts, d_wts, use_fabs, clamp, d_G6blk, d_mdiag);
+  WF_LAUNCH_CHECK();
+  return WF_OK;
+}
+
+template <int P>
+static int launch_stiffness_generic_t(int ncells, const int32_t* d_dofmap, const double* d_G6blk,
+                                      const double* d_D, const DMat& dm, double coeff, const double* d_x,
+                                      double* d_y, hipStream_t s)
+{
+  constexpr int n = P + 1, nd = n * n * n, CB = 256 / (n * n);
+  const unsigned nb = (unsigned)((ncells + CB - 1) / CB);
+  const size_t lds = (size_t)(3 * CB * nd + n * n) * sizeof(double);
+  hipLaunchKernelGGL(k_stiffness_generic<P>, dim3(nb), dim3(256), lds, s, ncells, d_dofmap,
+                     reinterpret_cast<const double2*>(d_G6blk), d_D, dm, coeff, d_x, d_y);
+  WF_LAUNCH_CHECK();
+  return WF_OK;
+}
+
+int launch_stiffness_generic(int P, int ncells, const int32_t* d_dofmap, const double* d_G6blk,
+                             const double* d_D, const DMat& dm, double coeff, const double* d_x, double* d_y,
+                             hipStream_t s)
+{
+  if (ncells == 0) return WF_OK;
+  switch (P) {
+    case 1: return launch_stiffness_generic_t<1>(ncells, d_dofmap, d_G6blk, d_D, dm, coeff, d_x, d_y, s);
+    case 2: return launch_stiffness_generic_t<2>(ncells, d_dofmap, d_G6blk, d_D, dm, coeff, d_x, d_y, s);
+    case 3: return launch_stiffness_generic_t<3>(ncells, d_dofmap, d_G6blk, d_D, dm, coeff, d_x, d_y, s);
+    case 4: return launch_stiffness_generic_t<4>(ncells, d_dofmap, d_G6blk, d_D, dm, coeff, d_x, d_y, s);
+    case 5: return launch_stiffness_generic_t<5>(ncells, d_dofmap, d_G6blk, d_D, dm, coeff, d_x, d_y, s);
+    case 6: return launch_stiffness_generic_t<6>(ncells, d_dofmap, d_G6blk, d_D, dm, coeff, d_x, d_y, s);
+    case 7: return launch_stiffness_generic_t<7>(ncells, d_dofmap, d_G6blk, d_D, dm, coeff, d_x, d_y, s);
+  }
+  set_error("stiffness: degree must be 1..7");
+  return WF_ERR_UNSUPPORTED;
+}
+
+template <int P>
+static int launch_stiffness_box_t(int nx, int ny, int nz, int bx, int by, int bz, const double* d_G6blk,
+                                  const double* d_D, const DMat& dm, double coeff, const double* d_x,
+                                  double* d_y, hipStream_t s)
+{
+  constexpr int n = P + 1, nd = n * n * n;
+  const int CB = bx * by * bz;
+  const int tile = (P * bx + 1) * (P * by + 1) * (P * bz + 1);
+  const unsigned nb = (unsigned)(((nx + bx - 1) / bx) * ((ny + by - 1) / by) * ((nz + bz - 1) / bz));
+  const size_t lds = (size_t)(((tile + 1) & ~1) + 2 * CB * nd + n * n) * sizeof(double);
+  hipLaunchKernelGGL(k_stiffness_box<P>, dim3(nb), dim3(256), lds, s, nx, ny, nz, bx, by, bz,
+                     reinterpret_cast<const double2*>(d_G6blk), d_D, dm, coeff, d_x, d_y);
+  WF_LAUNCH_CHECK();
+  return WF_OK;
+}
+
+int launch_stiffness_box(int P, int nx, int ny, int nz, int bx, int by, int bz, const double* d_G6blk,
+                         const double* d_D, const DMat& dm, double coeff, const double* d_x, double* d_y,
+                         hipStream_t s)
+{
+  if ((size_t)nx * ny * nz == 0) return WF_OK;
+  if (bx * by * bz * (P + 1) * (P + 1) > 256) {
+    set_error("stiffness_box: block does not fit a 256-thread workgroup");
+    return WF_ERR_INVALID;
+  }
+  switch (P) {
+    case 1: return launch_stiffness_box_t<1>(nx, ny, nz, bx, by, bz, d_G6blk, d_D, dm, coeff, d_x, d_y, s);
+    case 2: return launch_stiffness_box_t<2>(nx, ny, nz, bx, by, bz, d_G6blk, d_D, dm, coeff, d_x, d_y, s);
+    case 3: return launch_stiffness_box_t<3>(nx, ny, nz, bx, by, bz, d_G6blk, d_D, dm, coeff, d_x, d_y, s);
+    case 4: return launch_stiffness_box_t<4>(nx, ny, nz, bx, by, bz, d_G6blk, d_D, dm, coeff, d_x, d_y, s);
+    case 5: return launch_stiffness_box_t<5>(nx, ny, nz, bx, by, bz, d_G6blk, d_D, dm, coeff, d_x, d_y, s);
+    case 6: return launch_stiffness_box_t<6>(nx, ny, nz, bx, by, bz, d_G6blk, d_D, dm, coeff, d_x, d_y, s);
+    case 7: return launch_stiffness_box_t<7>(nx, ny, nz, bx, by, bz, d_G6blk, d_D, dm, coeff, d_x, d_y, s);
+  }
+  set_error("stiffness_box: degree must be 1..7");
+  return WF_ERR_UNSUPPORTED;
+}
+
+int launch_mass_lumped(int64_t nentries, const int32_t* d_dofmap, const double* d_detJ, const double* d_x,
+                       double* d_y, hipStream_t s)
+{
+  if (nentries == 0) return WF_OK;
+  hipLaunchKernelGGL(k_mass_lumped, dim3(grid_for((size_t)nentries, 256)), dim3(256), 0, s, nentries, d_dofmap,
+                     d_detJ, d_x, d_y);
+  WF_LAUNCH_CHECK();
+  return WF_OK;
+}
+
+int launch_mass_dense(int P, int nq1, int ncells, const int32_t* d_dofmap, const double* d_phi1,
+                      const double* d_detJ, const double* d_x, double* d_y, hipStream_t s)
+{
+  if (ncells == 0) return WF_OK;
+  const int n = P + 1, mx = n > nq1 ? n : nq1;
+  const size_t lds = (size_t)(2 * mx * mx * mx + nq1 * n) * sizeof(double);
+  if (lds > 160 * 1024) {
+    set_error("mass_dense: tables do not fit LDS");
+    return WF_ERR_UNSUPPORTED;
+  }
+  const unsigned nb = (unsigned)std::min<int64_t>(ncells, 256 * 8);
+  if (lds > 64 * 1024)
+    WF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mass_dense), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        (int)lds));
+  hipLaunchKernelGGL(k_mass_dense, dim3(nb), dim3(256), lds, s, n, nq1, ncells, d_dofmap, d_phi1, d_detJ, d_x,
+                     d_y);
+  WF_LAUNCH_CHECK();
+  return WF_OK;
+}
+
+}  // namespace wf

@@ -1,0 +1,212 @@
+// Streaming kernels of the RK4 loop and the free gather/scatter/transform
+// kernels (a8, a9, a15, a16).  All are HBM-bound; every kernel is
+// a grid-stride loop capped at 256 CUs x 8 workgroups, 16-byte accesses where
+// the operands allow it.
+#include "common.h"
+
+namespace wf {
+
+static inline unsigned capped_grid(size_t n, unsigned block)
+{
+  size_t g = (n + block - 1) / block;
+  const size_t cap = 256u * 8u;
+  return (unsigned)(g < cap ? (g ? g : 1) : cap);
+}
+
+#define WF_LAUNCH_CHECK()                                                       \
+  do {                                                                          \
+    hipError_t _e = hipGetLastError();                                          \
+    if (_e != hipSuccess) {                                                     \
+      set_error(std::string("kernel launch failed: ") + hipGetErrorString(_e)); \
+      return WF_ERR_HIP;                                                        \
+    }                                                                           \
+  } while (0)
+
+// common/cuda/scatter.cu:5-11
+__global__ void k_gather(int32_t N, const int32_t* __restrict__ idx, const double* __restrict__ in,
+                         double* __restrict__ out)
+{
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < N; g += (int64_t)gridDim.x * blockDim.x)
+    out[g] = in[idx[g]];
+}
+// common/cuda/scatter.cu:39-45 (hardware global_atomic_add_f64, no CAS loop)
+__global__ void k_scatter_add(int32_t N, const int32_t* __restrict__ idx, const double* __restrict__ in,
+                              double* __restrict__ out)
+{
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < N; g += (int64_t)gridDim.x * blockDim.x)
+    unsafeAtomicAdd(&out[idx[g]], in[g]);
+}
+__global__ void k_scatter_set(int32_t N, const int32_t* __restrict__ idx, const double* __restrict__ in,
+                              double* __restrict__ out)
+{
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < N; g += (int64_t)gridDim.x * blockDim.x)
+    out[idx[g]] = in[g];
+}
+// common/cuda/transform.cu:6-11
+__global__ void k_transform1(int32_t N, const double* __restrict__ in, const double* __restrict__ detJ,
+                             double* __restrict__ out)
+{
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < N; g += (int64_t)gridDim.x * blockDim.x)
+    out[g] = in[g] * detJ[g];
+}
+
+__global__ void k_fill(int64_t n, double v, double* __restrict__ out)
+{
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (int64_t)gridDim.x * blockDim.x)
+    out[g] = v;
+}
+// kernels::axpy of common/LinearGLL.hpp:28-33: r = x*alpha + y (r may alias y)
+__global__ void k_axpy(int64_t n, double alpha, const double* x, const double* y, double* r)
+{
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (int64_t)gridDim.x * blockDim.x)
+    r[g] = x[g] * alpha + y[g];
+}
+__global__ void k_scale(int64_t n, double alpha, double* x)
+{
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (int64_t)gridDim.x * blockDim.x)
+    x[g] *= alpha;
+}
+// common/LinearGLL.hpp:189-190: out = b / m
+__global__ void k_div(int64_t n, const double* b, const double* m, double* out)
+{
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (int64_t)gridDim.x * blockDim.x)
+    out[g] = b[g] / m[g];
+}
+__global__ void k_mult_add(int64_t n, const double* __restrict__ m, const double* __restrict__ x, double* y)
+{
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (int64_t)gridDim.x * blockDim.x)
+    y[g] += m[g] * x[g];
+}
+// common/cuda/la.hpp:87-103 inner_product: wave shuffle -> LDS -> one atomic per workgroup
+__global__ void k_dot(int64_t n, const double* __restrict__ x, const double* __restrict__ y,
+                      double* __restrict__ result)
+{
+  __shared__ double part[4];
+  double s = 0.0;
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (int64_t)gridDim.x * blockDim.x)
+    s += x[g] * y[g];
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) unsafeAtomicAdd(result, part[0] + part[1] + part[2] + part[3]);
+}
+// diagonal boundary operator, LinearGLL.hpp:175 / forms.ufl:19-24
+__global__ void k_boundary(int32_t n1, const int32_t* __restrict__ idx1, const double* __restrict__ m1,
+                           double s1, int32_t n2, const int32_t* __restrict__ idx2,
+                           const double* __restrict__ m2, double s2, const double* __restrict__ v,
+                           double* __restrict__ b)
+{
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < (int64_t)n1 + n2;
+       g += (int64_t)gridDim.x * blockDim.x) {
+    if (g < n1) {
+      unsafeAtomicAdd(&b[idx1[g]], s1 * m1[g]);
+    } else {
+      const int64_t h = g - n1;
+      const int32_t d = idx2[h];
+      unsafeAtomicAdd(&b[d], s2 * m2[h] * v[d]);
+    }
+  }
+}
+
+}  // namespace wf
+
+using namespace wf;
+
+extern "C" {
+
+int wf_gather(int32_t N, const int32_t* d_indices, const double* d_in, double* d_out, void* stream)
+{
+  if (N <= 0) return WF_OK;
+  hipLaunchKernelGGL(k_gather, dim3(capped_grid(N, 256)), dim3(256), 0, (hipStream_t)stream, N, d_indices, d_in,
+                     d_out);
+  WF_LAUNCH_CHECK();
+  return WF_OK;
+}
+int wf_scatter_add(int32_t N, const int32_t* d_indices, const double* d_in, double* d_out, void* stream)
+{
+  if (N <= 0) return WF_OK;
+  hipLaunchKernelGGL(k_scatter_add, dim3(capped_grid(N, 256)), dim3(256), 0, (hipStream_t)stream, N, d_indices,
+                     d_in, d_out);
+  WF_LAUNCH_CHECK();
+  return WF_OK;
+}
+int wf_scatter_set(int32_t N, const int32_t* d_indices, const double* d_in, double* d_out, void* stream)
+{
+  if (N <= 0) return WF_OK;
+  hipLaunchKernelGGL(k_scatter_set, dim3(capped_grid(N, 256)), dim3(256), 0, (hipStream_t)stream, N, d_indices,
+                     d_in, d_out);
+  WF_LAUNCH_CHECK();
+  return WF_OK;
+}
+int wf_transform1(int32_t N, const double* d_in, const double* d_detJ, double* d_out, void* stream)
+{
+  if (N <= 0) return WF_OK;
+  hipLaunchKernelGGL(k_transform1, dim3(capped_grid(N, 256)), dim3(256), 0, (hipStream_t)stream, N, d_in, d_detJ,
+                     d_out);
+  WF_LAUNCH_CHECK();
+  return WF_OK;
+}
+int wf_copy(int64_t n, const double* d_in, double* d_out, void* stream)
+{
+  if (n <= 0) return WF_OK;
+  WF_HIP_CHECK(hipMemcpyAsync(d_out, d_in, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice,
+                              (hipStream_t)stream));
+  return WF_OK;
+}
+int wf_fill(int64_t n, double value, double* d_out, void* stream)
+{
+  if (n <= 0) return WF_OK;
+  hipLaunchKernelGGL(k_fill, dim3(capped_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, n, value, d_out);
+  WF_LAUNCH_CHECK();
+  return WF_OK;
+}
+int wf_axpy(int64_t n, double alpha, const double* d_x, const double* d_y, double* d_r, void* stream)
+{
+  if (n <= 0) return WF_OK;
+  hipLaunchKernelGGL(k_axpy, dim3(capped_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, n, alpha, d_x, d_y,
+                     d_r);
+  WF_LAUNCH_CHECK();
+  return WF_OK;
+}
+int wf_scale(int64_t n, double alpha, double* d_x, void* stream)
+{
+  if (n <= 0) return WF_OK;
+  hipLaunchKernelGGL(k_scale, dim3(capped_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, n, alpha, d_x);
+  WF_LAUNCH_CHECK();
+  return WF_OK;
+}
+int wf_pointwise_div(int64_t n, const double* d_b, const double* d_m, double* d_out, void* stream)
+{
+  if (n <= 0) return WF_OK;
+  hipLaunchKernelGGL(k_div, dim3(capped_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, n, d_b, d_m, d_out);
+  WF_LAUNCH_CHECK();
+  return WF_OK;
+}
+int wf_pointwise_mult_add(int64_t n, const double* d_m, const double* d_x, double* d_y, void* stream)
+{
+  if (n <= 0) return WF_OK;
+  hipLaunchKernelGGL(k_mult_add, dim3(capped_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, n, d_m, d_x, d_y);
+  WF_LAUNCH_CHECK();
+  return WF_OK;
+}
+int wf_dot(int64_t n, const double* d_x, const double* d_y, double* d_result, void* stream)
+{
+  WF_HIP_CHECK(hipMemsetAsync(d_result, 0, sizeof(double), (hipStream_t)stream));
+  if (n <= 0) return WF_OK;
+  hipLaunchKernelGGL(k_dot, dim3(capped_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, n, d_x, d_y, d_result);
+  WF_LAUNCH_CHECK();
+  return WF_OK;
+}
+int wf_boundary_apply(int32_t n1, const int32_t* d_idx1, const double* d_m1, double s1, int32_t n2,
+                      const int32_t* d_idx2, const double* d_m2, double s2, const double* d_v, double* d_b,
+                      void* stream)
+{
+  const int64_t n = (int64_t)n1 + n2;
+  if (n <= 0) return WF_OK;
+  hipLaunchKernelGGL(k_boundary, dim3(capped_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, n1, d_idx1, d_m1,
+                     s1, n2, d_idx2, d_m2, s2, d_v, d_b);
+  WF_LAUNCH_CHECK();
+  return WF_OK;
+}
+
+}  // extern "C"

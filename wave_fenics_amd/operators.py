@@ -1,0 +1,287 @@
+"""Host-side mirror of the reference's operator classes on top of libwavehip.
+
+Same names, argument meaning and error behaviour as the reference:
+  StiffnessOperator(V, bdegree, params)      common/operators.hpp:137-201
+  MassOperatorLumped(V, bdegree)             common/operators.hpp:44-109 (MassOperatorCPU)
+  SpectralMassOperator(V, bdegree)           common/cuda/spectral_mass.hpp:24-100
+  MassOperator(V, element, quad_type, qd)    common/cuda/mass.hpp:18-107
+  gather / scatter / transform1              common/cuda/scatter.hpp, transform.hpp
+`op(x, y)` and `op.apply(x, y)` both compute y += A x on device vectors
+(torch.float64 CUDA tensors, or anything with data_ptr()).  Failures raise
+WavehipError (the reference throws std::runtime_error)."""
+from __future__ import annotations
+
+import ctypes
+from ctypes import POINTER, c_double, c_int32, c_void_p
+
+import numpy as np
+
+from . import _lib
+from ._lib import OpDesc, OpInfo, check, lib
+from .box import FunctionSpace
+
+
+def _ptr(t) -> int:
+    if isinstance(t, int):
+        return t
+    return int(t.data_ptr())
+
+
+def _stream(t=None) -> int:
+    """The HIP stream the call is ordered on: torch's current stream for the
+    tensor's device (plumbing only)."""
+    try:
+        import torch
+        if t is not None and hasattr(t, "is_cuda") and t.is_cuda:
+            return int(torch.cuda.current_stream(t.device).cuda_stream)
+    except ImportError:
+        pass
+    return 0
+
+
+def _check_vec(t, n: int, name: str):
+    if hasattr(t, "dtype"):
+        import torch
+        if t.dtype != torch.float64 or not t.is_cuda or not t.is_contiguous():
+            raise _lib.WavehipError(f"{name}: expected a contiguous float64 device vector")
+        if t.numel() < n:
+            raise _lib.WavehipError(f"{name}: vector has {t.numel()} entries, operator needs {n}")
+
+
+def _dp(a):
+    return None if a is None else a.ctypes.data_as(POINTER(c_double))
+
+
+def _ip(a):
+    return None if a is None else a.ctypes.data_as(POINTER(c_int32))
+
+
+# ---------------------------------------------------------------------------
+# setup functions (a1, a2)
+# ---------------------------------------------------------------------------
+def tabulate_gll(p: int):
+    """1-D GLL points, weights and collocation derivative matrix D[q][a]."""
+    n = p + 1
+    pts, wts, D = np.zeros(n), np.zeros(n), np.zeros((n, n))
+    check(lib().wf_tabulate_gll(p, _dp(pts), _dp(wts), _dp(D)))
+    return pts, wts, D
+
+
+def tabulate_dense(p: int):
+    """tabulate_basis_and_permutation (common/operators.hpp:13-32): returns
+    (perm, table[4][nq][nd]); perm is the identity in this engine's ordering."""
+    nd = (p + 1) ** 3
+    table = np.zeros((4, nd, nd))
+    check(lib().wf_tabulate_dense(p, _dp(table)))
+    return np.arange(nd, dtype=np.int32), table
+
+
+def precompute_geometric_data(mesh, p: int, use_fabs: bool = True, clamp: bool = True, want_G: bool = True):
+    """precompute_geometric_data (common/precomputation.hpp:18-110) on the device;
+    returns host arrays (G[ncells][nq][3][3], detJ[ncells][nq])."""
+    nq = (p + 1) ** 3
+    x = np.ascontiguousarray(mesh.x, dtype=np.float64)
+    gd = np.ascontiguousarray(mesh.geom_dofmap, dtype=np.int32)
+    G = np.zeros((mesh.ncells, nq, 3, 3)) if want_G else None
+    detJ = np.zeros((mesh.ncells, nq))
+    check(lib().wf_geometry_hex(p, mesh.ncells, x.shape[0], _dp(x), _ip(gd), int(use_fabs), int(clamp),
+                                _dp(G), _dp(detJ)))
+    return G, detJ
+
+
+# ---------------------------------------------------------------------------
+# operator handles
+# ---------------------------------------------------------------------------
+class _Operator:
+    _kind = None
+
+    def __init__(self):
+        self._h = c_void_p()
+
+    def _create(self, desc: OpDesc, keep=()):
+        self._keep = keep
+        check(lib().wf_op_create(ctypes.byref(desc), ctypes.byref(self._h)))
+        self._keep = ()
+        self._info()
+
+    def _create_box(self, kind: int, p: int, mesh, c0: float, flags: int):
+        nx, ny, nz = mesh.n
+        x = np.ascontiguousarray(mesh.x, dtype=np.float64)
+        check(lib().wf_op_create_box(kind, p, nx, ny, nz, _dp(x), float(c0), flags, ctypes.byref(self._h)))
+        self._info()
+
+    def _info(self):
+        info = OpInfo()
+        check(lib().wf_op_info(self._h, ctypes.byref(info)))
+        self.info = info
+
+    # introspection as common/cuda/mass.hpp:68-71
+    def num_quads(self): return self.info.num_quads
+    def num_cells(self): return self.info.num_cells
+    def num_dofs(self): return self.info.num_dofs_cell
+    def flops(self): return self.info.flops
+    def alg_bytes(self): return self.info.alg_bytes
+
+    def apply(self, x, y, stream: int | None = None):
+        """y += A x (accumulate; the caller zeroes y, LinearGLL.hpp:173)."""
+        _check_vec(x, self.info.ndofs, "x")
+        _check_vec(y, self.info.ndofs, "y")
+        s = _stream(x) if stream is None else stream
+        check(lib().wf_op_apply(self._h, _ptr(x), _ptr(y), s))
+
+    __call__ = apply
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib().wf_op_destroy(self._h)
+            self._h = c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _base_desc(V: FunctionSpace, kind: int, degree: int, perm=None):
+    d = OpDesc()
+    d.kind = kind
+    d.degree = degree
+    d.ncells = V.mesh.ncells
+    d.ndofs = V.ndofs
+    keep = []
+    dm = np.ascontiguousarray(V.dofmap, dtype=np.int32)
+    if dm.shape != (V.mesh.ncells, (degree + 1) ** 3):
+        raise _lib.WavehipError("dofmap shape does not match ncells x (degree+1)^3")
+    keep.append(dm)
+    d.h_dofmap = _ip(dm)
+    if perm is not None:
+        pm = np.ascontiguousarray(perm, dtype=np.int32)
+        keep.append(pm)
+        d.h_perm = _ip(pm)
+    return d, keep
+
+
+def _attach_mesh(d: OpDesc, V: FunctionSpace, keep: list):
+    x = np.ascontiguousarray(V.mesh.x, dtype=np.float64)
+    gd = np.ascontiguousarray(V.mesh.geom_dofmap, dtype=np.int32)
+    keep += [x, gd]
+    d.nverts = x.shape[0]
+    d.h_xverts = _dp(x)
+    d.h_geom_dofmap = _ip(gd)
+
+
+class StiffnessOperator(_Operator):
+    """StiffnessOperator(V, bdegree, params) -- common/operators.hpp:137-201.
+
+    params["c0"] is honoured (the reference hard-codes 1500, operators.hpp:114,
+    which is the only value its caller passes).  G=None computes the geometry on
+    the device from V.mesh (precomputation.hpp:69-107); a host array in the
+    reference layout [ncells][nq][3][3] is used as given.
+    structured=None picks the implicit-dofmap box kernel when V says its dofmap
+    is the lexicographic box numbering; structured=False forces the generic
+    (arbitrary dofmap, atomic scatter) kernel."""
+
+    def __init__(self, V: FunctionSpace, bdegree: int, params: dict | None = None, G=None, perm=None,
+                 structured: bool | None = None, flags: int = 0):
+        super().__init__()
+        c0 = 1500.0 if not params else float(params.get("c0", 1500.0))
+        self.c0 = c0
+        if structured is None:
+            structured = bool(getattr(V, "structured", False)) and G is None and perm is None
+        if structured:
+            if bdegree != V.degree:
+                raise _lib.WavehipError("structured operator: bdegree must equal the space's degree")
+            self._create_box(_lib.WF_OP_STIFFNESS, bdegree, V.mesh, c0, flags)
+            return
+        d, keep = _base_desc(V, _lib.WF_OP_STIFFNESS, bdegree, perm)
+        d.c0 = c0
+        d.flags = flags
+        if G is not None:
+            Gc = np.ascontiguousarray(G, dtype=np.float64)
+            if Gc.size != V.mesh.ncells * (bdegree + 1) ** 3 * 9:
+                raise _lib.WavehipError("G must be [ncells][nq][3][3]")
+            keep.append(Gc)
+            d.h_G = _dp(Gc)
+        else:
+            _attach_mesh(d, V, keep)
+        self._create(d, keep)
+
+
+class MassOperatorLumped(_Operator):
+    """MassOperatorCPU(V, bdegree) -- common/operators.hpp:44-109: the GLL-lumped
+    mass y += M x.  detJ = |det J| w (fabs), as precompute_geometric_data."""
+
+    def __init__(self, V: FunctionSpace, bdegree: int, detJ=None, perm=None, structured: bool | None = None,
+                 flags: int = 0):
+        super().__init__()
+        if structured is None:
+            structured = bool(getattr(V, "structured", False)) and detJ is None and perm is None
+        if structured:
+            self._create_box(_lib.WF_OP_MASS_LUMPED, bdegree, V.mesh, 0.0, flags)
+            return
+        d, keep = _base_desc(V, _lib.WF_OP_MASS_LUMPED, bdegree, perm)
+        d.flags = flags
+        if detJ is not None:
+            Dc = np.ascontiguousarray(detJ, dtype=np.float64)
+            keep.append(Dc)
+            d.h_detJ = _dp(Dc)
+        else:
+            _attach_mesh(d, V, keep)
+        self._create(d, keep)
+
+
+class SpectralMassOperator(MassOperatorLumped):
+    """SpectralMassOperator(V, bdegree) -- common/cuda/spectral_mass.hpp:24-100.
+    Same lumped mass; detJ = det(J) w WITHOUT fabs (spectral_mass.hpp:58-64 via
+    precompute.hpp:102-116).  Degrees outside 2..7 are rejected like the
+    reference's qdegree map (spectral_mass.hpp:42-48)."""
+
+    def __init__(self, V: FunctionSpace, bdegree: int, structured: bool | None = None):
+        if bdegree < 2 or bdegree > 7:
+            raise _lib.WavehipError("SpectralMassOperator: degree must be 2..7")
+        super().__init__(V, bdegree, structured=structured, flags=_lib.WF_FLAG_NO_FABS)
+
+
+class MassOperator(_Operator):
+    """MassOperator(V, element, quad_type, qd) -- common/cuda/mass.hpp:18-107:
+    y += Phi^T diag(detJ w) Phi x with a tensor-product rule.  `phi1` is the 1-D
+    interpolation matrix [nq1][P+1] of the element at the 1-D rule's points and
+    detJ [ncells][nq1^3] the scaled determinants (mass.hpp:35-39)."""
+
+    def __init__(self, V: FunctionSpace, degree: int, phi1: np.ndarray, detJ: np.ndarray, perm=None):
+        super().__init__()
+        d, keep = _base_desc(V, _lib.WF_OP_MASS_DENSE, degree, perm)
+        p1 = np.ascontiguousarray(phi1, dtype=np.float64)
+        Dc = np.ascontiguousarray(detJ, dtype=np.float64)
+        if p1.ndim != 2 or p1.shape[1] != degree + 1:
+            raise _lib.WavehipError("phi1 must be [nq1][degree+1]")
+        if Dc.size != V.mesh.ncells * p1.shape[0] ** 3:
+            raise _lib.WavehipError("detJ must be [ncells][nq1^3]")
+        keep += [p1, Dc]
+        d.nq1 = p1.shape[0]
+        d.h_phi1 = _dp(p1)
+        d.h_detJ = _dp(Dc)
+        self._create(d, keep)
+
+
+# ---------------------------------------------------------------------------
+# free kernels (common/cuda/scatter.hpp:7-14, transform.hpp:7-8)
+# ---------------------------------------------------------------------------
+def gather(N: int, indices, inp, out, block_size: int = 512, stream: int | None = None):
+    """out[i] = in[indices[i]] (block_size accepted for signature parity, unused)."""
+    check(lib().wf_gather(N, _ptr(indices), _ptr(inp), _ptr(out), _stream(inp) if stream is None else stream))
+
+
+def scatter(N: int, indices, inp, out, block_size: int = 512, stream: int | None = None):
+    """out[indices[i]] += in[i] (hardware fp64 atomics)."""
+    check(lib().wf_scatter_add(N, _ptr(indices), _ptr(inp), _ptr(out), _stream(inp) if stream is None else stream))
+
+
+def scatter_set(N: int, indices, inp, out, stream: int | None = None):
+    check(lib().wf_scatter_set(N, _ptr(indices), _ptr(inp), _ptr(out), _stream(inp) if stream is None else stream))
+
+
+def transform1(N: int, inp, detJ, out, block_size: int = 512, stream: int | None = None):
+    """out[i] = in[i] * detJ[i]."""
+    check(lib().wf_transform1(N, _ptr(inp), _ptr(detJ), _ptr(out), _stream(inp) if stream is None else stream))
