@@ -98,9 +98,11 @@ def test_stiffness_generic_permuted_dofmap(gpu, oracle):
                                        (4, (4, 4, 4), "1,1,1"), (2, (7, 5, 4), "3,3,3"), (3, (5, 4, 3), "4,2,2"),
                                        (1, (9, 5, 5), "4,4,4"), (5, (3, 2, 2), "7,1,1"), (6, (3, 2, 2), "5,1,1"),
                                        (7, (2, 2, 1), "2,2,1")])
-def test_stiffness_box_vs_oracle(gpu, oracle, p, n, block, monkeypatch):
-    """Structured (implicit dofmap) kernel incl. partial blocks at the mesh end."""
+def test_stiffness_box_block_vs_oracle(gpu, oracle, p, n, block, monkeypatch):
+    """Structured (implicit dofmap) single-pass block kernel incl. partial blocks
+    at the mesh end."""
     import wave_fenics_amd as w
+    monkeypatch.setenv("WF_BOX_KERNEL", "block")
     monkeypatch.setenv("WF_BOX_BLOCK", block)
     om, mesh, V = make(oracle, n, p)
     K = oracle.StiffnessOperator(om, p)
@@ -111,6 +113,41 @@ def test_stiffness_box_vs_oracle(gpu, oracle, p, n, block, monkeypatch):
     K(x, yref)
     op = w.StiffnessOperator(V, p, {"c0": 1500.0}, structured=True)
     assert op.info.structured == 1
+    y = dev(y0, gpu)
+    op(dev(x, gpu), y)
+    assert relerr(y.cpu().numpy(), yref) <= 1e-11
+
+
+@pytest.mark.parametrize("p,n,variant,lz", [
+    (4, (7, 5, 6), 0, 2), (4, (7, 5, 6), 1, 4), (4, (3, 3, 5), 2, 1), (4, (6, 6, 7), 0, 100), (4, (4, 2, 3), 1, 3),
+    (1, (9, 9, 5), 0, 2), (1, (5, 4, 3), 1, 1), (1, (17, 5, 4), 2, 3),
+    (2, (7, 6, 5), 0, 2), (2, (4, 4, 4), 1, 3), (2, (8, 5, 3), 2, 2),
+    (3, (5, 5, 4), 0, 3), (3, (4, 4, 3), 1, 2), (3, (5, 3, 3), 2, 1),
+    (5, (4, 3, 3), 0, 2), (5, (3, 3, 2), 1, 1), (5, (8, 2, 2), 2, 2),
+    (6, (3, 3, 3), 0, 2), (6, (6, 2, 2), 1, 1), (6, (4, 2, 2), 2, 3),
+    (7, (3, 3, 2), 0, 1), (7, (5, 2, 2), 1, 2), (7, (3, 2, 3), 2, 2)])
+def test_stiffness_march_vs_oracle(gpu, oracle, p, n, variant, lz, monkeypatch):
+    """The production box kernel (marching columns): every compiled column
+    cross-section, partial columns at the mesh end, z segments of 1..all layers,
+    accumulate semantics."""
+    import wave_fenics_amd as w
+    monkeypatch.setenv("WF_BOX_KERNEL", "march")
+    monkeypatch.setenv("WF_MARCH_VARIANT", str(variant))
+    monkeypatch.setenv("WF_MARCH_LZ", str(lz))
+    om, mesh, V = make(oracle, n, p)
+    K = oracle.StiffnessOperator(om, p)
+    rng = np.random.default_rng(2024)
+    x = rng.uniform(-1, 1, om.ndofs)
+    y0 = rng.uniform(-1, 1, om.ndofs) * 1e6
+    yref = y0.copy()
+    K(x, yref)
+    op = w.StiffnessOperator(V, p, {"c0": 1500.0}, structured=True)
+    y = dev(y0, gpu)
+    op(dev(x, gpu), y)
+    assert relerr(y.cpu().numpy(), yref) <= 1e-11
+    # default segmentation as well
+    monkeypatch.delenv("WF_MARCH_LZ")
+    op = w.StiffnessOperator(V, p, {"c0": 1500.0}, structured=True)
     y = dev(y0, gpu)
     op(dev(x, gpu), y)
     assert relerr(y.cpu().numpy(), yref) <= 1e-11

@@ -13,6 +13,7 @@ struct wf_op {
   int kind = 0, P = 0, n = 0, nd = 0, nq = 0, ncells = 0, ndofs = 0;
   int structured = 0, nx = 0, ny = 0, nz = 0, bx = 1, by = 1, bz = 1;
   int nq1 = 0;
+  int march = 0, march_variant = 0, lz = 1;   // marching box kernel (stiffness_march.hip)
   double coeff = 0.0;
   DMat dm{};
   int32_t* d_dofmap = nullptr;
@@ -369,6 +370,27 @@ int wf_op_create_box(int kind, int degree, int nx, int ny, int nz, const double*
   op->nz = nz;
   op->coeff = -1.0 * c0 * c0;
   default_box_block(P, &op->bx, &op->by, &op->bz);
+  if (kind == WF_OP_STIFFNESS) {
+    // production kernel: marching columns (stiffness_march.hip).  Tuning hooks:
+    // WF_BOX_KERNEL=block selects the single-pass block kernel, WF_MARCH_VARIANT
+    // the compiled column cross-section, WF_MARCH_LZ the layers per z segment.
+    const char* kern = std::getenv("WF_BOX_KERNEL");
+    op->march = !(kern && std::strcmp(kern, "block") == 0);
+    if (op->march) {
+      const char* v = std::getenv("WF_MARCH_VARIANT");
+      static const int kDefaultVariant[8] = {0, 0, 0, 0, 1, 0, 0, 0};   // P4: 5x2 columns (measured fastest)
+      op->march_variant = v ? std::atoi(v) : kDefaultVariant[P];
+      if (!march_variant(P, op->march_variant, &op->bx, &op->by)) {
+        set_error("wf_op_create_box: WF_MARCH_VARIANT out of range");
+        return WF_ERR_INVALID;
+      }
+      op->bz = 1;
+      const int ncols = ((nx + op->bx - 1) / op->bx) * ((ny + op->by - 1) / op->by);
+      int nseg = std::max(1, std::min(nz, (1536 + ncols / 2) / ncols));
+      op->lz = (nz + nseg - 1) / nseg;
+      if (const char* l = std::getenv("WF_MARCH_LZ")) op->lz = std::max(1, std::atoi(l));
+    }
+  }
   int rc;
 
   std::vector<double> D(n * n);
@@ -410,6 +432,9 @@ int wf_op_apply(wf_op* op, const double* d_x, double* d_y, void* stream)
   WF_REQUIRE(op && d_x && d_y, "wf_op_apply: null argument");
   hipStream_t s = (hipStream_t)stream;
   if (op->structured) {
+    if (op->kind == WF_OP_STIFFNESS && op->march)
+      return launch_stiffness_march(op->P, op->march_variant, op->nx, op->ny, op->nz, op->lz, op->d_G6blk, op->d_D,
+                                    op->dm, op->coeff, d_x, d_y, s);
     if (op->kind == WF_OP_STIFFNESS)
       return launch_stiffness_box(op->P, op->nx, op->ny, op->nz, op->bx, op->by, op->bz, op->d_G6blk, op->d_D, op->dm,
                                   op->coeff, d_x, d_y, s);

@@ -14,6 +14,8 @@
 // stream; it is stored pre-blocked per workgroup so that every lane issues
 // 16-byte loads that are contiguous across the wave, and all loads of a batch
 // are issued before any arithmetic.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace wf {
@@ -205,73 +207,9 @@ __global__ void k_geometry_box(int n, int nx, int ny, int nz, int bx, int by, in
   }
 }
 
-// --------------------------------------------------------------------------
-// stiffness: per-thread core shared by the generic and the box kernel
-// --------------------------------------------------------------------------
-// U: LDS dofs of this thread's cell, addressed U[k*sk + j*sj + i] (strides in
-// doubles; the generic kernel uses the compact cell layout sk = n^2, sj = n,
-// the box kernel addresses the cell inside the block's dof tile).
-// Fr, Fs: LDS scratch of the cell, compact layout.  sD: LDS copy of D.
-// Output: out[k] = (K_cell u)[i, j, k].  Two workgroup barriers inside.
-template <int P>
-__device__ __forceinline__ void stiffness_column(const double* __restrict__ U, int sk, int sj,
-                                                 double* __restrict__ Fr, double* __restrict__ Fs,
-                                                 const double* __restrict__ sD, const DMat& dm,
-                                                 const double2 (&g)[P + 1][3], double coeff, int i,
-                                                 int j, bool active, double (&out)[P + 1])
-{
-  constexpr int n = P + 1, n2 = n * n;
-  double ft[n];
-  if (active) {
-    double ru[n];
-#pragma unroll
-    for (int k = 0; k < n; ++k) ru[k] = U[k * sk + j * sj + i];
-    double di[n], dj[n];
-#pragma unroll
-    for (int a = 0; a < n; ++a) {
-      di[a] = sD[i * n + a];
-      dj[a] = sD[j * n + a];
-    }
-#pragma unroll
-    for (int k = 0; k < n; ++k) {
-      double ur = 0.0, us = 0.0, ut = 0.0;
-#pragma unroll
-      for (int a = 0; a < n; ++a) {
-        ur += di[a] * U[k * sk + j * sj + a];
-        us += dj[a] * U[k * sk + a * sj + i];
-        ut += dm.v[k * n + a] * ru[a];
-      }
-      const double g00 = g[k][0].x, g01 = g[k][0].y, g02 = g[k][1].x, g11 = g[k][1].y,
-                   g12 = g[k][2].x, g22 = g[k][2].y;
-      // operators.hpp:126-128: fw = coeff * (G row . w)
-      const double fr = coeff * (g00 * ur + g01 * us + g02 * ut);
-      const double fs = coeff * (g01 * ur + g11 * us + g12 * ut);
-      ft[k] = coeff * (g02 * ur + g12 * us + g22 * ut);
-      Fr[k * n2 + j * n + i] = fr;
-      Fs[k * n2 + j * n + i] = fs;
-    }
-  }
-  __syncthreads();
-  if (active) {
-    double dti[n], dtj[n];
-#pragma unroll
-    for (int a = 0; a < n; ++a) {
-      dti[a] = sD[a * n + i];
-      dtj[a] = sD[a * n + j];
-    }
-#pragma unroll
-    for (int k = 0; k < n; ++k) {
-      double s = 0.0;
-#pragma unroll
-      for (int a = 0; a < n; ++a) {
-        s += dti[a] * Fr[k * n2 + j * n + a];
-        s += dtj[a] * Fs[k * n2 + a * n + i];
-        s += dm.v[a * n + k] * ft[a];
-      }
-      out[k] = s;
-    }
-  }
-}
+}  // namespace wf
+#include "stiffness_core.h"  // stiffness_column<P>
+namespace wf {
 
 // --------------------------------------------------------------------------
 // generic stiffness: arbitrary tensor-ordered dofmap, atomic scatter
@@ -281,7 +219,7 @@ __global__ __launch_bounds__(256) void k_stiffness_generic(int ncells, const int
                                                            const double2* __restrict__ G6blk,
                                                            const double* __restrict__ dD, DMat dm,
                                                            double coeff, const double* __restrict__ x,
-                                                           double* __restrict__ y)
+                                                           double* __restrict__ y, int ablate)
 {
   constexpr int n = P + 1, n2 = n * n, nd = n * n2;
   constexpr int CB = 256 / n2, NT = CB * n2;
@@ -303,6 +241,7 @@ __global__ __launch_bounds__(256) void k_stiffness_generic(int ncells, const int
   double2 g[n][3];
   if (active) {
     const double2* gp = G6blk + (batch * n * 3) * (size_t)NT + t;
+    if (ablate & 2) gp = G6blk + t;   // diagnostic: every workgroup re-reads batch 0 (L2-resident)
 #pragma unroll
     for (int k = 0; k < n; ++k)
 #pragma unroll
@@ -319,7 +258,7 @@ __global__ __launch_bounds__(256) void k_stiffness_generic(int ncells, const int
     idx[m] = -1;
     if (pos < nvalid) {
       idx[m] = dofmap[(size_t)cell0 * nd + pos];
-      U[pos] = x[idx[m]];
+      U[pos] = (ablate & 4) ? 1.0 + idx[m] : x[idx[m]];
     } else if (pos < CB * nd) {
       U[pos] = 0.0;
     }
@@ -327,7 +266,7 @@ __global__ __launch_bounds__(256) void k_stiffness_generic(int ncells, const int
   __syncthreads();
 
   double out[n];
-  stiffness_column<P>(U + cl * nd, n2, n, Fr + cl * nd, Fs + cl * nd, sD, dm, g, coeff, i, j, active, out);
+  stiffness_column<P>(U + cl * nd, n2, n, Fr + cl * nd, Fs + cl * nd, sD, dm, g, coeff, i, j, active, out, ablate);
 
   // 3. element results back through LDS (Fr is free after the second barrier
   //    only for this thread's own entries -> use U, whose reads all precede the
@@ -340,7 +279,13 @@ __global__ __launch_bounds__(256) void k_stiffness_generic(int ncells, const int
 #pragma unroll
   for (int m = 0; m < NFLAT; ++m) {
     const int pos = t + 256 * m;
-    if (idx[m] >= 0) unsafeAtomicAdd(&y[idx[m]], U[pos]);
+    if (idx[m] >= 0) {
+      if (ablate & 1) {   // diagnostic: no scatter (store kept live, never taken)
+        if (U[pos] == 1.2345e300) y[idx[m]] = U[pos];
+      } else {
+        unsafeAtomicAdd(&y[idx[m]], U[pos]);
+      }
+    }
   }
 }
 
@@ -353,7 +298,7 @@ __global__ __launch_bounds__(256) void k_stiffness_box(int nx, int ny, int nz, i
                                                        const double2* __restrict__ G6blk,
                                                        const double* __restrict__ dD, DMat dm,
                                                        double coeff, const double* __restrict__ x,
-                                                       double* __restrict__ y)
+                                                       double* __restrict__ y, int ablate)
 {
   constexpr int n = P + 1, n2 = n * n, nd = n * n2;
   const int CB = bx * by * bz, NT = CB * n2;
@@ -377,6 +322,7 @@ __global__ __launch_bounds__(256) void k_stiffness_box(int nx, int ny, int nz, i
   double2 g[n][3];
   if (inrange) {
     const double2* gp = G6blk + ((size_t)blockIdx.x * n * 3) * (size_t)NT + t;
+    if (ablate & 2) gp = G6blk + t;
 #pragma unroll
     for (int k = 0; k < n; ++k)
 #pragma unroll
@@ -392,14 +338,14 @@ __global__ __launch_bounds__(256) void k_stiffness_box(int nx, int ny, int nz, i
     const int I = pos % TX, J = (pos / TX) % TY, K = pos / (TX * TY);
     double v = 0.0;
     if (I < EX && J < EY && K < EZ)
-      v = x[(size_t)(I0 + I) + (size_t)NX * ((size_t)(J0 + J) + (size_t)NY * (K0 + K))];
+      v = (ablate & 4) ? 1.0 + pos : x[(size_t)(I0 + I) + (size_t)NX * ((size_t)(J0 + J) + (size_t)NY * (K0 + K))];
     Ut[pos] = v;
   }
   __syncthreads();
 
   double out[n];
   const double* Uc = Ut + (P * lz) * TX * TY + (P * ly) * TX + P * lx;
-  stiffness_column<P>(Uc, TX * TY, TX, Fr + cl * nd, Fs + cl * nd, sD, dm, g, coeff, i, j, active, out);
+  stiffness_column<P>(Uc, TX * TY, TX, Fr + cl * nd, Fs + cl * nd, sD, dm, g, coeff, i, j, active, out, ablate);
 
   // y tile: zero, accumulate the cells of the block with LDS atomics
   __syncthreads();
@@ -423,7 +369,9 @@ __global__ __launch_bounds__(256) void k_stiffness_box(int nx, int ny, int nz, i
       const bool shared = (sx0 && I == 0) || (sx1 && I == TX - 1) || (sy0 && J == 0) || (sy1 && J == TY - 1)
                           || (sz0 && K == 0) || (sz1 && K == TZ - 1);
       const double v = Ut[pos];
-      if (shared)
+      if (ablate & 1) {
+        if (v == 1.2345e300) y[gidx] = v;
+      } else if (shared)
         unsafeAtomicAdd(&y[gidx], v);
       else
         y[gidx] += v;
@@ -525,6 +473,14 @@ __global__ __launch_bounds__(256) void k_mass_dense(int n, int m, int ncells,
 // --------------------------------------------------------------------------
 // launchers
 // --------------------------------------------------------------------------
+// Diagnostic ablation mask (profiling only; WF_ABLATE unset or 0 in production):
+// 1 = no scatter, 2 = geometry served from L2, 4 = no x gather, 8 = no contractions.
+static int ablate_flags()
+{
+  const char* e = std::getenv("WF_ABLATE");
+  return e ? std::atoi(e) : 0;
+}
+
 static inline unsigned grid_for(size_t n, unsigned block) { return (unsigned)((n + block - 1) / block); }
 
 #define WF_LAUNCH_CHECK()                                                       \
@@ -582,7 +538,7 @@ static int launch_stiffness_generic_t(int ncells, const int32_t* d_dofmap, const
   const unsigned nb = (unsigned)((ncells + CB - 1) / CB);
   const size_t lds = (size_t)(3 * CB * nd + n * n) * sizeof(double);
   hipLaunchKernelGGL(k_stiffness_generic<P>, dim3(nb), dim3(256), lds, s, ncells, d_dofmap,
-                     reinterpret_cast<const double2*>(d_G6blk), d_D, dm, coeff, d_x, d_y);
+                     reinterpret_cast<const double2*>(d_G6blk), d_D, dm, coeff, d_x, d_y, ablate_flags());
   WF_LAUNCH_CHECK();
   return WF_OK;
 }
@@ -616,7 +572,7 @@ static int launch_stiffness_box_t(int nx, int ny, int nz, int bx, int by, int bz
   const unsigned nb = (unsigned)(((nx + bx - 1) / bx) * ((ny + by - 1) / by) * ((nz + bz - 1) / bz));
   const size_t lds = (size_t)(((tile + 1) & ~1) + 2 * CB * nd + n * n) * sizeof(double);
   hipLaunchKernelGGL(k_stiffness_box<P>, dim3(nb), dim3(256), lds, s, nx, ny, nz, bx, by, bz,
-                     reinterpret_cast<const double2*>(d_G6blk), d_D, dm, coeff, d_x, d_y);
+                     reinterpret_cast<const double2*>(d_G6blk), d_D, dm, coeff, d_x, d_y, ablate_flags());
   WF_LAUNCH_CHECK();
   return WF_OK;
 }

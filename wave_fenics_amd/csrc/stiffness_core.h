@@ -1,0 +1,85 @@
+// Per-thread core of the sum-factorised hexahedral stiffness operator, shared by
+// the generic, box and marching kernels.
+#pragma once
+#include "common.h"
+
+namespace wf {
+
+// --------------------------------------------------------------------------
+// stiffness: per-thread core shared by the generic and the box kernel
+// --------------------------------------------------------------------------
+// U: LDS dofs of this thread's cell, addressed U[k*sk + j*sj + i] (strides in
+// doubles; the generic kernel uses the compact cell layout sk = n^2, sj = n,
+// the box kernel addresses the cell inside the block's dof tile).
+// Fr, Fs: LDS scratch of the cell, compact layout.  sD: LDS copy of D.
+// Output: out[k] = (K_cell u)[i, j, k].  Two workgroup barriers inside.
+template <int P>
+__device__ __forceinline__ void stiffness_column(const double* __restrict__ U, int sk, int sj,
+                                                 double* __restrict__ Fr, double* __restrict__ Fs,
+                                                 const double* __restrict__ sD, const DMat& dm,
+                                                 const double2 (&g)[P + 1][3], double coeff, int i,
+                                                 int j, bool active, double (&out)[P + 1], int ablate = 0)
+{
+  constexpr int n = P + 1, n2 = n * n;
+  double ft[n];
+  if (ablate & 8) {   // diagnostic: no contractions, keep every input live
+    if (active) {
+#pragma unroll
+      for (int k = 0; k < n; ++k)
+        out[k] = U[k * sk + j * sj + i] + g[k][0].x + g[k][0].y + g[k][1].x + g[k][1].y + g[k][2].x + g[k][2].y;
+    }
+    __syncthreads();
+    return;
+  }
+  if (active) {
+    double ru[n];
+#pragma unroll
+    for (int k = 0; k < n; ++k) ru[k] = U[k * sk + j * sj + i];
+    double di[n], dj[n];
+#pragma unroll
+    for (int a = 0; a < n; ++a) {
+      di[a] = sD[i * n + a];
+      dj[a] = sD[j * n + a];
+    }
+#pragma unroll
+    for (int k = 0; k < n; ++k) {
+      double ur = 0.0, us = 0.0, ut = 0.0;
+#pragma unroll
+      for (int a = 0; a < n; ++a) {
+        ur += di[a] * U[k * sk + j * sj + a];
+        us += dj[a] * U[k * sk + a * sj + i];
+        ut += dm.v[k * n + a] * ru[a];
+      }
+      const double g00 = g[k][0].x, g01 = g[k][0].y, g02 = g[k][1].x, g11 = g[k][1].y,
+                   g12 = g[k][2].x, g22 = g[k][2].y;
+      // operators.hpp:126-128: fw = coeff * (G row . w)
+      const double fr = coeff * (g00 * ur + g01 * us + g02 * ut);
+      const double fs = coeff * (g01 * ur + g11 * us + g12 * ut);
+      ft[k] = coeff * (g02 * ur + g12 * us + g22 * ut);
+      Fr[k * n2 + j * n + i] = fr;
+      Fs[k * n2 + j * n + i] = fs;
+    }
+  }
+  __syncthreads();
+  if (active) {
+    double dti[n], dtj[n];
+#pragma unroll
+    for (int a = 0; a < n; ++a) {
+      dti[a] = sD[a * n + i];
+      dtj[a] = sD[a * n + j];
+    }
+#pragma unroll
+    for (int k = 0; k < n; ++k) {
+      double s = 0.0;
+#pragma unroll
+      for (int a = 0; a < n; ++a) {
+        s += dti[a] * Fr[k * n2 + j * n + a];
+        s += dtj[a] * Fs[k * n2 + a * n + i];
+        s += dm.v[a * n + k] * ft[a];
+      }
+      out[k] = s;
+    }
+  }
+}
+
+}  // namespace wf

@@ -1,0 +1,281 @@
+// Structured-box stiffness operator, "marching" form: the production kernel for
+// y += -c0^2 K x on lexicographically numbered box meshes.
+//
+// One 256-thread workgroup owns a column of BX x BY cells and marches through
+// `lz` cell layers in z.  Per layer it runs the column-thread sum-factorised
+// core (stiffness_core.h) on BX*BY cells at once and
+//   * streams the layer's symmetric geometry (the dominant HBM stream, 48 B per
+//     point) straight into registers with 16-byte lane-contiguous loads, issued
+//     one full layer AHEAD of its use (register double buffer), together with the
+//     next layer's x planes and the y values this layer will update, so HBM
+//     latency never sits on the per-layer critical path;
+//   * keeps the z-direction partial sums of the shared dof plane in a register
+//     (the same thread owns the same (i, j) column in every layer), combines the
+//     cells of the layer through an LDS tile without LDS atomics (fixed order),
+//     and adds the finished planes to y with hardware fp64 atomics
+//     (global_atomic_add_f64, no return) in whole lattice rows: one atomic per
+//     tile dof and layer instead of one per element-local dof (1.2 instead of
+//     1.95 atomics per dof at P4), issued as contiguous runs of P*BX+1 doubles.
+//     Measured on MI355X: mixing plain read-modify-write of column-interior dofs
+//     with atomics on the column faces (which share 128-byte lines) is ~2x
+//     slower than making every update an atomic, so every update is an atomic.
+// Reference semantics: StiffnessOperator::operator() (common/operators.hpp:183-200),
+// y accumulated, coefficient -c0^2 (operators.hpp:114-115).
+#include <cstdlib>
+
+#include "stiffness_core.h"
+
+namespace wf {
+
+template <int P, int BX, int BY>
+__global__ __launch_bounds__(256, (P <= 4 ? 2 : 1)) void k_stiffness_march(int nx, int ny, int nz, int lz,
+                                                            const double2* __restrict__ G6blk,
+                                                            const double* __restrict__ dD, DMat dm,
+                                                            double coeff, const double* __restrict__ x,
+                                                            double* __restrict__ y, int ablate)
+{
+  constexpr int n = P + 1, n2 = n * n, nd = n * n2;
+  constexpr int CB = BX * BY, NT = CB * n2;
+  constexpr int TX = P * BX + 1, TY = P * BY + 1, TP = TX * TY;
+  constexpr int NPOS = (P * TP + 255) / 256;        // flush / x-prefetch positions per thread
+  constexpr int NPOS0 = ((P + 1) * TP + 255) / 256; // prologue x positions per thread
+  constexpr int NCP = (TP + 255) / 256;             // positions of one plane per thread
+  static_assert(NT <= 256, "column does not fit a 256-thread workgroup");
+
+  __shared__ __attribute__((aligned(16))) double Ux[(P + 1) * TP];   // x planes of the layer
+  __shared__ __attribute__((aligned(16))) double O[CB * P * n2];     // per-cell results, planes 0..P-1
+  __shared__ __attribute__((aligned(16))) double Fr[CB * nd];
+  __shared__ __attribute__((aligned(16))) double Fs[CB * nd];
+  __shared__ __attribute__((aligned(16))) double sD[n * n];
+
+  const int t = threadIdx.x;
+  const int nbx = (nx + BX - 1) / BX, nby = (ny + BY - 1) / BY;
+  const int ncols = nbx * nby;
+  const int col = blockIdx.x % ncols, seg = blockIdx.x / ncols;
+  const int Bx = col % nbx, By = col / nbx;
+  const int z0 = seg * lz, z1 = min(nz, z0 + lz);
+  const bool active = t < NT;
+  const int cl = t / n2, ji = t % n2, j = ji / n, i = ji % n;
+  const int lx = cl % BX, ly = cl / BX;
+
+  const int NX = P * nx + 1, NY = P * ny + 1;
+  const size_t plane = (size_t)NX * NY;
+  const int I0 = P * Bx * BX, J0 = P * By * BY;
+  const int EX = min(TX, NX - I0), EY = min(TY, NY - J0);
+
+  // ---- per-thread tile positions (identical in every layer) -----------------
+  // position m: (I, J, pl) with pl in [0, P); flush: lattice plane P*kz + pl;
+  // x prefetch of the next layer: LDS plane pl + 1, lattice plane P*(kz+1) + pl + 1.
+  int32_t poff[NPOS];   // lattice offset of (I0+I, J0+J, pl) relative to the layer's first plane; -1 = outside
+#pragma unroll
+  for (int m = 0; m < NPOS; ++m) {
+    const int pos = t + 256 * m;
+    const int pl = pos / TP, r = pos % TP, J = r / TX, I = r % TX;
+    poff[m] = -1;
+    if (pos < P * TP && I < EX && J < EY)
+      poff[m] = (int32_t)((size_t)(I0 + I) + (size_t)NX * (J0 + J) + plane * pl);
+  }
+
+  // ---- prologue: geometry of layer z0 -> registers, x planes 0..P -> LDS ------
+  double2 gcur[n][3], gnext[n][3];
+  auto load_g = [&](double2 (&g)[n][3], int kz) {
+    size_t blk = (size_t)Bx + (size_t)nbx * (By + (size_t)nby * kz);
+    if (ablate & 2) blk = 0;   // diagnostic: geometry served from L2
+    const double2* gp = G6blk + (blk * n * 3) * (size_t)NT + t;
+#pragma unroll
+    for (int k = 0; k < n; ++k)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) g[k][p] = gp[(size_t)(k * 3 + p) * NT];
+  };
+  if (active) load_g(gcur, z0);
+  if (t < n * n) sD[t] = dD[t];
+  {
+    const size_t base = plane * (size_t)(P * z0);
+#pragma unroll
+    for (int m = 0; m < NPOS0; ++m) {
+      const int pos = t + 256 * m;
+      if (pos < (P + 1) * TP) {
+        const int pl = pos / TP, r = pos % TP, J = r / TX, I = r % TX;
+        double v = 0.0;
+        if (I < EX && J < EY) {
+          const size_t gi = base + (size_t)(I0 + I) + (size_t)NX * (J0 + J) + plane * pl;
+          v = (ablate & 4) ? 1.0 + pos : x[gi];
+        }
+        Ux[pos] = v;
+      }
+    }
+  }
+  __syncthreads();
+
+  double carry = 0.0;
+  const double* Uc = Ux + (P * ly) * TX + P * lx;
+
+  for (int kz = z0; kz < z1; ++kz) {
+    const bool has_next = kz + 1 < z1;
+    const size_t base = plane * (size_t)(P * kz);   // first lattice plane of this layer
+
+    // (a) next layer's x planes and geometry: in flight during this layer's arithmetic
+    double xn[NPOS];
+#pragma unroll
+    for (int m = 0; m < NPOS; ++m) {
+      xn[m] = 0.0;
+      if (has_next && poff[m] >= 0) {
+        const size_t gi = base + plane * (P + 1) + poff[m];
+        xn[m] = (ablate & 4) ? 1.0 + m : x[gi];
+      }
+    }
+    if (has_next && active) load_g(gnext, kz + 1);
+
+    // (b) element kernels of the layer
+    double out[n];
+    stiffness_column<P>(Uc, TP, TX, Fr + cl * nd, Fs + cl * nd, sD, dm, gcur, coeff, i, j, active, out, ablate);
+    double xcp[NCP];
+#pragma unroll
+    for (int m = 0; m < NCP; ++m) {
+      const int pos = t + 256 * m;
+      xcp[m] = pos < TP ? Ux[P * TP + pos] : 0.0;
+    }
+    if (active) {
+      out[0] += carry;        // z-shared plane: partial sum of the layer below
+      carry = out[P];
+#pragma unroll
+      for (int k = 0; k < P; ++k) O[(cl * P + k) * n2 + ji] = out[k];
+    }
+    __syncthreads();
+
+    // (c) combine the cells of the layer (fixed order) and add the finished planes to y
+#pragma unroll
+    for (int m = 0; m < NPOS; ++m) {
+      if (poff[m] < 0) continue;
+      const int pos = t + 256 * m;
+      const int pl = pos / TP, r = pos % TP, J = r / TX, I = r % TX;
+      const int ca = I / P, ia = I % P, cb = J / P, jb = J % P;
+      double v = 0.0;
+      if (cb < BY) {
+        if (ca < BX) v += O[((cb * BX + ca) * P + pl) * n2 + jb * n + ia];
+        if (ia == 0 && ca > 0) v += O[((cb * BX + ca - 1) * P + pl) * n2 + jb * n + P];
+      }
+      if (jb == 0 && cb > 0) {
+        if (ca < BX) v += O[(((cb - 1) * BX + ca) * P + pl) * n2 + P * n + ia];
+        if (ia == 0 && ca > 0) v += O[(((cb - 1) * BX + ca - 1) * P + pl) * n2 + P * n + P];
+      }
+      double* dst = y + base + poff[m];
+      if (ablate & 1) {
+        if (v == 1.2345e300) *dst = v;
+      } else {
+        unsafeAtomicAdd(dst, v);
+      }
+    }
+
+    // (d) rotate the x planes and the geometry registers
+    if (has_next) {
+#pragma unroll
+      for (int m = 0; m < NCP; ++m) {
+        const int pos = t + 256 * m;
+        if (pos < TP) Ux[pos] = xcp[m];
+      }
+#pragma unroll
+      for (int m = 0; m < NPOS; ++m) {
+        const int pos = t + 256 * m;
+        if (pos < P * TP) Ux[TP + pos] = xn[m];
+      }
+#pragma unroll
+      for (int k = 0; k < n; ++k)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) gcur[k][p] = gnext[k][p];
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: the last (carried) plane ------------------------------------
+  if (active) O[cl * n2 + ji] = carry;
+  __syncthreads();
+  {
+    const size_t base = plane * (size_t)(P * z1);
+#pragma unroll
+    for (int m = 0; m < NCP; ++m) {
+      const int pos = t + 256 * m;
+      if (pos >= TP) continue;
+      const int J = pos / TX, I = pos % TX;
+      if (I >= EX || J >= EY) continue;
+      const int ca = I / P, ia = I % P, cb = J / P, jb = J % P;
+      double v = 0.0;
+      if (cb < BY) {
+        if (ca < BX) v += O[(cb * BX + ca) * n2 + jb * n + ia];
+        if (ia == 0 && ca > 0) v += O[(cb * BX + ca - 1) * n2 + jb * n + P];
+      }
+      if (jb == 0 && cb > 0) {
+        if (ca < BX) v += O[((cb - 1) * BX + ca) * n2 + P * n + ia];
+        if (ia == 0 && ca > 0) v += O[((cb - 1) * BX + ca - 1) * n2 + P * n + P];
+      }
+      double* dst = y + base + (size_t)(I0 + I) + (size_t)NX * (J0 + J);
+      if (ablate & 1) {
+        if (v == 1.2345e300) *dst = v;
+      } else {
+        unsafeAtomicAdd(dst, v);
+      }
+    }
+  }
+}
+
+static int march_ablate()
+{
+  const char* e = std::getenv("WF_ABLATE");
+  return e ? std::atoi(e) : 0;
+}
+
+template <int P, int BX, int BY>
+static int launch_march_t(int nx, int ny, int nz, int lz, const double* d_G6blk, const double* d_D,
+                          const DMat& dm, double coeff, const double* d_x, double* d_y, hipStream_t s)
+{
+  const int ncols = ((nx + BX - 1) / BX) * ((ny + BY - 1) / BY);
+  const int nseg = (nz + lz - 1) / lz;
+  hipLaunchKernelGGL((k_stiffness_march<P, BX, BY>), dim3((unsigned)(ncols * nseg)), dim3(256), 0, s, nx, ny, nz,
+                     lz, reinterpret_cast<const double2*>(d_G6blk), d_D, dm, coeff, d_x, d_y, march_ablate());
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error(std::string("stiffness_march launch failed: ") + hipGetErrorString(e));
+    return WF_ERR_HIP;
+  }
+  return WF_OK;
+}
+
+// The (BX, BY) column cross-sections compiled per degree.  index = variant.
+bool march_variant(int P, int variant, int* bx, int* by)
+{
+  static const int tab[8][3][2] = {
+      {{0, 0}, {0, 0}, {0, 0}},
+      {{8, 8}, {4, 4}, {8, 4}},   // P1: 64 / 16 / 32 cells
+      {{5, 5}, {3, 3}, {7, 4}},   // P2: 25 / 9 / 28 cells
+      {{4, 4}, {3, 3}, {4, 2}},   // P3: 16 / 9 / 8 cells
+      {{3, 3}, {5, 2}, {2, 2}},   // P4: 9 / 10 / 4 cells
+      {{3, 2}, {2, 2}, {7, 1}},   // P5: 6 / 4 / 7 cells
+      {{2, 2}, {5, 1}, {3, 1}},   // P6: 4 / 5 / 3 cells
+      {{2, 2}, {4, 1}, {2, 1}},   // P7: 4 / 4 / 2 cells
+  };
+  if (P < 1 || P > 7 || variant < 0 || variant > 2) return false;
+  *bx = tab[P][variant][0];
+  *by = tab[P][variant][1];
+  return true;
+}
+
+#define WF_MARCH_CASE(PP, V, BXX, BYY) \
+  if (P == PP && variant == V) return launch_march_t<PP, BXX, BYY>(nx, ny, nz, lz, d_G6blk, d_D, dm, coeff, d_x, d_y, s);
+
+int launch_stiffness_march(int P, int variant, int nx, int ny, int nz, int lz, const double* d_G6blk,
+                           const double* d_D, const DMat& dm, double coeff, const double* d_x, double* d_y,
+                           hipStream_t s)
+{
+  if ((size_t)nx * ny * nz == 0) return WF_OK;
+  WF_MARCH_CASE(1, 0, 8, 8) WF_MARCH_CASE(1, 1, 4, 4) WF_MARCH_CASE(1, 2, 8, 4)
+  WF_MARCH_CASE(2, 0, 5, 5) WF_MARCH_CASE(2, 1, 3, 3) WF_MARCH_CASE(2, 2, 7, 4)
+  WF_MARCH_CASE(3, 0, 4, 4) WF_MARCH_CASE(3, 1, 3, 3) WF_MARCH_CASE(3, 2, 4, 2)
+  WF_MARCH_CASE(4, 0, 3, 3) WF_MARCH_CASE(4, 1, 5, 2) WF_MARCH_CASE(4, 2, 2, 2)
+  WF_MARCH_CASE(5, 0, 3, 2) WF_MARCH_CASE(5, 1, 2, 2) WF_MARCH_CASE(5, 2, 7, 1)
+  WF_MARCH_CASE(6, 0, 2, 2) WF_MARCH_CASE(6, 1, 5, 1) WF_MARCH_CASE(6, 2, 3, 1)
+  WF_MARCH_CASE(7, 0, 2, 2) WF_MARCH_CASE(7, 1, 4, 1) WF_MARCH_CASE(7, 2, 2, 1)
+  set_error("stiffness_march: unsupported degree/variant");
+  return WF_ERR_UNSUPPORTED;
+}
+
+}  // namespace wf
