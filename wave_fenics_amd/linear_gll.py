@@ -80,7 +80,8 @@ def facet_lumped_mass(V, tag_of_face, tag: int):
 
 class LinearGLLOpt:
     def __init__(self, V, degreeOfBasis: int, speedOfSound: float, sourceFrequency: float,
-                 pressureAmplitude: float, boundary=None, updater=None, device=None, structured=None):
+                 pressureAmplitude: float, boundary=None, updater=None, device=None, structured=None,
+                 tags=None):
         self.V = V
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
         self.k_ = degreeOfBasis
@@ -105,7 +106,8 @@ class LinearGLLOpt:
             self.updater.scatter_fwd(self.m)   # keep ghost entries of m non-zero and consistent for b/m
         # LinearGLL.hpp:113-115: the boundary form
         if boundary is None:
-            tags = {0: 1, 1: 2, 2: 2, 3: 2, 4: 2, 5: 2}
+            if tags is None:
+                tags = {0: 1, 1: 2, 2: 2, 3: 2, 4: 2, 5: 2}
             i1, m1 = facet_lumped_mass(V, tags, 1)
             i2, m2 = facet_lumped_mass(V, tags, 2)
         else:
