@@ -97,11 +97,19 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # WF_BENCH_BACKEND=gloo is a rehearsal hook for a one-GPU box (ranks share the
+    # card, halo staged through the host); the driver's multi-GPU run uses nccl = RCCL.
+    backend = os.environ.get("WF_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank if backend == "nccl" else local_rank % max(ndev, 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     p, n = args.degree, args.size
     updater = None
@@ -182,7 +190,7 @@ def main():
         achieved = alg / (kern_ms * 1e-3) / 1e9
         traffic = None
         tp = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tp):
+        if os.path.exists(tp) and p == 4 and n == 54 and not args.generic:
             try:
                 with open(tp) as f:
                     traffic = json.load(f).get("stiffness_hbm_bytes_per_launch")

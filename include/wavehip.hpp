@@ -1,0 +1,256 @@
+// wavehip.hpp -- header-only C++17 wrappers over the C ABI (wavehip.h) that keep
+// the reference's class names, constructor arguments and apply semantics, so
+// that reference-side code (common/LinearGLL.hpp, the demo mains) can switch by
+// changing an include.  Exceptions: the C ABI never throws; these wrappers
+// re-throw std::runtime_error exactly where the reference does
+// (common/cuda/array.hpp:15-17,33-35; mass.hpp:91-92; utils.hpp:30-34).
+//
+// The operator classes are templated on a Vector concept satisfied by
+// dolfinx::la::Vector<T, Alloc> (x.array().data(), y.mutable_array().data());
+// the vectors must live in device memory (hipMalloc; see wavehip::allocator).
+// The function-space argument of the reference is replaced by a plain
+// `wavehip::Space` aggregate; INTEGRATION.md shows how to fill it from a
+// dolfinx::fem::FunctionSpace.
+#pragma once
+
+#include <cstdint>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "wavehip.h"
+
+namespace wavehip {
+
+inline void check(int rc)
+{
+  if (rc != WF_OK) throw std::runtime_error(std::string("wavehip: ") + wf_last_error());
+}
+
+// ---- utils::set_device (common/cuda/utils.hpp:22-38) ----------------------
+inline int set_device(int rank)
+{
+  check(wf_set_device(rank));
+  return rank;
+}
+
+// ---- cuda::array<T> (common/cuda/array.hpp:8-51) ---------------------------
+template <class T>
+class array {
+public:
+  array() = default;
+  explicit array(std::size_t size) : _size(size) { check(wf_malloc(reinterpret_cast<void**>(&_data), size * sizeof(T))); }
+  array(const array&) = delete;
+  array& operator=(const array&) = delete;
+  array(array&& o) noexcept : _data(o._data), _size(o._size) { o._data = nullptr; o._size = 0; }
+  ~array() { wf_free(_data); }
+  std::size_t size() const { return _size; }
+  const T* data() const { return _data; }
+  T* data() { return _data; }
+  template <class Container>
+  void set(const Container& source)
+  {
+    if (source.size() != _size) throw std::runtime_error("wavehip::array::set: size mismatch");
+    check(wf_memcpy_h2d(_data, source.data(), _size * sizeof(T)));
+  }
+  std::vector<T> copy_to_host() const
+  {
+    std::vector<T> h(_size);
+    check(wf_memcpy_d2h(h.data(), _data, _size * sizeof(T)));
+    return h;
+  }
+
+private:
+  T* _data = nullptr;
+  std::size_t _size = 0;
+};
+
+// ---- CUDA::allocator<T> (common/cuda/allocator.hpp:9-40) -------------------
+// std-allocator over device memory for dolfinx::la::Vector<T, Alloc>.  The
+// reference uses managed memory; MI355X-native code uses explicit device buffers,
+// so host code must not dereference vectors allocated with it.
+template <class T>
+struct allocator {
+  using value_type = T;
+  allocator() = default;
+  template <class U>
+  allocator(const allocator<U>&) noexcept {}
+  T* allocate(std::size_t n)
+  {
+    void* p = nullptr;
+    check(wf_malloc(&p, n * sizeof(T)));
+    return static_cast<T*>(p);
+  }
+  void deallocate(T* p, std::size_t) noexcept { wf_free(p); }
+  template <class U>
+  bool operator==(const allocator<U>&) const noexcept { return true; }
+  template <class U>
+  bool operator!=(const allocator<U>&) const noexcept { return false; }
+};
+
+// ---- free kernels (common/cuda/scatter.hpp:7-14, transform.hpp:7-8) --------
+template <typename T>
+void gather(std::int32_t N, const std::int32_t* indices, const T* in, T* out, int /*block_size*/ = 512, void* stream = nullptr)
+{
+  check(wf_gather(N, indices, in, out, stream));
+}
+template <typename T>
+void scatter(std::int32_t N, const std::int32_t* indices, const T* in, T* out, int /*block_size*/ = 512, void* stream = nullptr)
+{
+  check(wf_scatter_add(N, indices, in, out, stream));
+}
+template <typename T>
+void transform1(std::int32_t N, const T* in, const T* detJ, T* out, int /*block_size*/ = 512, void* stream = nullptr)
+{
+  check(wf_transform1(N, in, detJ, out, stream));
+}
+
+// What the operators need from a dolfinx::fem::FunctionSpace (host arrays).
+struct Space {
+  int degree = 0;
+  std::int32_t ncells = 0;                  // mesh->topology().index_map(tdim)->size_local()
+  std::int32_t ndofs = 0;                   // index_map->size_local() + num_ghosts()
+  const std::int32_t* dofmap = nullptr;     // V->dofmap()->list().array().data(), [ncells][nd]
+  const std::int32_t* perm = nullptr;       // element.get_tensor_product_representation()[0] perm, or nullptr
+  std::int32_t nverts = 0;
+  const double* x = nullptr;                // mesh->geometry().x().data(), [nverts][3]
+  const std::int32_t* geom_dofmap = nullptr;// mesh->geometry().dofmap().array().data(), [ncells][8]
+};
+
+namespace detail {
+class OpBase {
+public:
+  OpBase() = default;
+  OpBase(const OpBase&) = delete;
+  OpBase& operator=(const OpBase&) = delete;
+  ~OpBase() { wf_op_destroy(_op); }
+  std::size_t num_quads() const { return info().num_quads; }
+  std::size_t num_cells() const { return info().num_cells; }
+  std::size_t num_dofs() const { return info().num_dofs_cell; }
+  double flops() const { return info().flops; }
+
+  /// y += A x   (common/operators.hpp:183, common/cuda/mass.hpp:76)
+  template <typename Vector>
+  void apply(const Vector& x, Vector& y, void* stream = nullptr)
+  {
+    check(wf_op_apply(_op, x.array().data(), y.mutable_array().data(), stream));
+  }
+  template <typename Vector>
+  void operator()(const Vector& x, Vector& y) { apply(x, y); }
+  void apply(const double* d_x, double* d_y, void* stream = nullptr) { check(wf_op_apply(_op, d_x, d_y, stream)); }
+
+protected:
+  wf_op_info_t info() const
+  {
+    wf_op_info_t i{};
+    check(wf_op_info(_op, &i));
+    return i;
+  }
+  static wf_op_desc base_desc(const Space& V, int kind, int degree)
+  {
+    wf_op_desc d{};
+    d.kind = kind;
+    d.degree = degree;
+    d.ncells = V.ncells;
+    d.ndofs = V.ndofs;
+    d.h_dofmap = V.dofmap;
+    d.h_perm = V.perm;
+    d.nverts = V.nverts;
+    d.h_xverts = V.x;
+    d.h_geom_dofmap = V.geom_dofmap;
+    return d;
+  }
+  wf_op* _op = nullptr;
+};
+}  // namespace detail
+
+/// StiffnessOperator(V, bdegree, params) -- common/operators.hpp:137-201
+template <typename T>
+class StiffnessOperator : public detail::OpBase {
+  static_assert(sizeof(T) == sizeof(double), "fp64 only");
+
+public:
+  StiffnessOperator(const Space& V, int bdegree, std::map<std::string, double>& params)
+  {
+    wf_op_desc d = base_desc(V, WF_OP_STIFFNESS, bdegree);
+    auto it = params.find("c0");
+    d.c0 = it == params.end() ? 1500.0 : it->second;   // operators.hpp:114
+    check(wf_op_create(&d, &_op));
+  }
+};
+
+/// MassOperatorCPU(V, bdegree) -- common/operators.hpp:44-109 (the `MassOperator`
+/// that common/LinearGLL.hpp:63,105 instantiates)
+template <typename T>
+class MassOperatorLumped : public detail::OpBase {
+public:
+  MassOperatorLumped(const Space& V, int bdegree, int flags = WF_FLAG_NONE)
+  {
+    wf_op_desc d = base_desc(V, WF_OP_MASS_LUMPED, bdegree);
+    d.flags = flags;
+    check(wf_op_create(&d, &_op));
+  }
+};
+
+/// SpectralMassOperator(V, bdegree) -- common/cuda/spectral_mass.hpp:24-100
+template <typename T>
+class SpectralMassOperator : public MassOperatorLumped<T> {
+public:
+  SpectralMassOperator(const Space& V, int bdegree) : MassOperatorLumped<T>(check_degree(V, bdegree), bdegree, WF_FLAG_NO_FABS) {}
+
+private:
+  static const Space& check_degree(const Space& V, int bdegree)
+  {
+    if (bdegree < 2 || bdegree > 7) throw std::runtime_error("SpectralMassOperator: degree must be 2..7");
+    return V;
+  }
+};
+
+/// MassOperator(V, element, quad_type, qd) -- common/cuda/mass.hpp:18-107.
+/// phi1: 1-D interpolation matrix [nq1][degree+1]; detJ: [ncells][nq1^3] (host).
+template <typename T>
+class MassOperator : public detail::OpBase {
+public:
+  MassOperator(const Space& V, int degree, int nq1, const double* phi1, const double* detJ)
+  {
+    wf_op_desc d = base_desc(V, WF_OP_MASS_DENSE, degree);
+    d.nq1 = nq1;
+    d.h_phi1 = phi1;
+    d.h_detJ = detJ;
+    check(wf_op_create(&d, &_op));
+  }
+};
+
+/// Structured box operators (mesh::create_box with this engine's numbering).
+template <typename T>
+class BoxStiffnessOperator : public detail::OpBase {
+public:
+  BoxStiffnessOperator(int degree, int nx, int ny, int nz, const double* xverts, double c0)
+  {
+    check(wf_op_create_box(WF_OP_STIFFNESS, degree, nx, ny, nz, xverts, c0, WF_FLAG_NONE, &_op));
+  }
+};
+
+// ---- linalg:: (common/cuda/la.hpp:31-138) and kernels:: (LinearGLL.hpp:15-35)
+namespace linalg {
+template <typename Vector>
+void copy(const Vector& x, Vector& y, void* stream = nullptr)
+{
+  check(wf_copy((std::int64_t)x.array().size(), x.array().data(), y.mutable_array().data(), stream));
+}
+template <typename Scalar, typename Vector>
+void axpy(Scalar alpha, const Vector& x, Vector& y, void* stream = nullptr)   // y = alpha x + y over size_local
+{
+  check(wf_axpy((std::int64_t)x.map()->size_local(), (double)alpha, x.array().data(), y.array().data(),
+                y.mutable_array().data(), stream));
+}
+template <typename Scalar, typename Vector>
+void scale(Scalar alpha, Vector& x, void* stream = nullptr)
+{
+  check(wf_scale((std::int64_t)x.map()->size_local(), (double)alpha, x.mutable_array().data(), stream));
+}
+}  // namespace linalg
+
+}  // namespace wavehip

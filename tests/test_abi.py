@@ -75,3 +75,18 @@ def test_box_mesh_matches_oracle(oracle):
         V = w.create_functionspace(m, p)
         assert np.array_equal(m.x, om.x) and np.array_equal(m.geom_dofmap, om.geom_dofmap)
         assert np.array_equal(V.dofmap, om.dofmap) and V.ndofs == om.ndofs
+
+
+def test_cxx_wrappers_compile_and_link(wlib, tmp_path):
+    """include/wavehip.hpp (the reference-named C++ classes) compiles with g++
+    and links against libwavehip.so; the host-only calls run."""
+    import subprocess
+    exe = str(tmp_path / "wrapper_smoke")
+    libdir = os.path.join(ROOT, "wave_fenics_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cxx", "wrapper_smoke.cpp"), "-o", exe,
+                           "-L", libdir, "-lwavehip", f"-Wl,-rpath,{libdir}"])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stderr
+    a, b = out.stdout.split()
+    assert abs(float(a) - 0.1726731646460114) < 1e-15 and abs(float(b) - 13.513004977448478) < 1e-12

@@ -49,7 +49,7 @@ def main():
                 os.environ.pop("WF_MARCH_LZ", None)
         ops[spec] = w.StiffnessOperator(V, p, structured=True)
     alg = ops["generic"].alg_bytes()
-    masks = [0, 1, 2, 4, 8, 3, 5, 7, 15]
+    masks = [int(v) for v in os.environ.get("MASKS", "0,1,2,4,8,3,5,7,15").split(",")]
     print(f"P{p} N{n} ndofs {V.ndofs} alg_bytes {alg/1e6:.1f} MB")
     print("kernel".ljust(16) + "".join(f"{m:>9d}" for m in masks))
     for name, op in ops.items():
