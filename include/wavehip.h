@@ -134,11 +134,21 @@ int wf_op_create_box(int kind, int degree, int nx, int ny, int nz,
  * spectral_mass.hpp:84. */
 int wf_op_apply(wf_op* op, const double* d_x, double* d_y, void* stream);
 
+/* Interior / interface split of a box stiffness operator on a domain-decomposed
+ * mesh: lets the caller overlap the forward ghost update
+ * (VectorUpdater::update_fwd_begin/_end, demo/gpu_scatter_mpi/VectorUpdater.hpp:106-143)
+ * with the cells that read no ghost value.  ghost_*0 != 0 marks the lower lattice
+ * plane of that axis as a ghost plane.  apply(INTERIOR) + apply(INTERFACE) == apply. */
+typedef enum { WF_PART_ALL = 0, WF_PART_INTERIOR = 1, WF_PART_INTERFACE = 2 } wf_part;
+int wf_op_set_ghost_faces(wf_op* op, int ghost_x0, int ghost_y0, int ghost_z0);
+int wf_op_apply_part(wf_op* op, const double* d_x, double* d_y, int part, void* stream);
+
 typedef struct {
   int kind, degree, num_cells, num_dofs_cell, num_quads, ndofs, structured;
   double flops;          /* reference model 4*ncells*nq*nd (mass.hpp:71)        */
   double alg_bytes;      /* algorithmic HBM bytes per apply          */
   size_t device_bytes;   /* device memory owned by the operator                  */
+  int items_interior, items_interface; /* work items per part (wf_op_set_ghost_faces) */
 } wf_op_info_t;
 int wf_op_info(const wf_op* op, wf_op_info_t* info); /* num_quads()/num_cells()/... mass.hpp:68-71 */
 int wf_op_destroy(wf_op* op);

@@ -153,6 +153,41 @@ def test_stiffness_march_vs_oracle(gpu, oracle, p, n, variant, lz, monkeypatch):
     assert relerr(y.cpu().numpy(), yref) <= 1e-11
 
 
+@pytest.mark.parametrize("ghost", [(1, 0, 0), (0, 1, 1), (1, 1, 1), (0, 0, 0)])
+def test_interior_interface_split(gpu, oracle, ghost, monkeypatch):
+    """apply(INTERIOR) + apply(INTERFACE) == apply, and the interior part reads
+    no ghost plane of x (poisoned with NaN)."""
+    import torch
+    import wave_fenics_amd as w
+    from wave_fenics_amd._lib import WF_PART_INTERFACE, WF_PART_INTERIOR
+    monkeypatch.setenv("WF_MARCH_LZ", "2")
+    p, n = 4, (11, 5, 6)
+    om, mesh, V = make(oracle, n, p)
+    op = w.StiffnessOperator(V, p, {"c0": 1500.0}, structured=True)
+    assert op.set_ghost_faces(*[bool(g) for g in ghost])
+    assert op.info.items_interior + op.info.items_interface > 0
+    rng = np.random.default_rng(8)
+    x = dev(rng.uniform(-1, 1, om.ndofs), gpu)
+    yall = torch.zeros_like(x)
+    op(x, yall)
+    ya = torch.zeros_like(x)
+    xp = x.clone().reshape(V.lattice[2], V.lattice[1], V.lattice[0])
+    if ghost[0]:
+        xp[:, :, 0] = float("nan")
+    if ghost[1]:
+        xp[:, 0, :] = float("nan")
+    if ghost[2]:
+        xp[0, :, :] = float("nan")
+    op.apply_part(xp.reshape(-1).contiguous(), ya, WF_PART_INTERIOR)
+    assert bool(torch.isfinite(ya).all()), "interior part read a ghost plane"
+    op.apply_part(x, ya, WF_PART_INTERFACE)
+    assert relerr(ya.cpu().numpy(), yall.cpu().numpy()) <= 1e-13
+    if ghost == (0, 0, 0):
+        assert op.info.items_interface == 0
+    opg = w.StiffnessOperator(V, p, structured=False)
+    assert opg.set_ghost_faces(True, False, False) is False      # generic kernel: unsplit sequence
+
+
 def test_geometry_vs_oracle(gpu, oracle):
     import wave_fenics_amd as w
     for p, n in [(2, (3, 3, 2)), (4, (2, 2, 2))]:

@@ -30,11 +30,13 @@ class OpInfo(ctypes.Structure):
         ("kind", c_int), ("degree", c_int), ("num_cells", c_int), ("num_dofs_cell", c_int),
         ("num_quads", c_int), ("ndofs", c_int), ("structured", c_int),
         ("flops", c_double), ("alg_bytes", c_double), ("device_bytes", c_size_t),
+        ("items_interior", c_int), ("items_interface", c_int),
     ]
 
 
 WF_OP_STIFFNESS, WF_OP_MASS_LUMPED, WF_OP_MASS_DENSE = 0, 1, 2
 WF_FLAG_NONE, WF_FLAG_NO_FABS, WF_FLAG_NO_CLAMP = 0, 1, 2
+WF_PART_ALL, WF_PART_INTERIOR, WF_PART_INTERFACE = 0, 1, 2
 
 # every symbol include/wavehip.h declares: name -> (restype, argtypes)
 _dp, _ip, _vp = POINTER(c_double), POINTER(c_int32), c_void_p
@@ -57,6 +59,8 @@ SIGNATURES = {
     "wf_op_create": (c_int, [POINTER(OpDesc), POINTER(c_void_p)]),
     "wf_op_create_box": (c_int, [c_int, c_int, c_int, c_int, c_int, _dp, c_double, c_int, POINTER(c_void_p)]),
     "wf_op_apply": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "wf_op_set_ghost_faces": (c_int, [c_void_p, c_int, c_int, c_int]),
+    "wf_op_apply_part": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "wf_op_info": (c_int, [c_void_p, POINTER(OpInfo)]),
     "wf_op_destroy": (c_int, [c_void_p]),
     "wf_gather": (c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -22,6 +22,9 @@ struct wf_op {
   double* d_D = nullptr;
   double* d_phi1 = nullptr;
   double* d_mdiag = nullptr;
+  int32_t* d_items[2] = {nullptr, nullptr};   // [0] interior, [1] interface work items (marching kernel)
+  int nitems[2] = {0, 0};
+  int have_parts = 0;
   size_t device_bytes = 0;
 };
 
@@ -65,6 +68,8 @@ void free_op(wf_op* op)
   (void)hipFree(op->d_D);
   (void)hipFree(op->d_phi1);
   (void)hipFree(op->d_mdiag);
+  (void)hipFree(op->d_items[0]);
+  (void)hipFree(op->d_items[1]);
   delete op;
 }
 
@@ -434,7 +439,7 @@ int wf_op_apply(wf_op* op, const double* d_x, double* d_y, void* stream)
   if (op->structured) {
     if (op->kind == WF_OP_STIFFNESS && op->march)
       return launch_stiffness_march(op->P, op->march_variant, op->nx, op->ny, op->nz, op->lz, op->d_G6blk, op->d_D,
-                                    op->dm, op->coeff, d_x, d_y, s);
+                                    op->dm, op->coeff, d_x, d_y, nullptr, 0, s);
     if (op->kind == WF_OP_STIFFNESS)
       return launch_stiffness_box(op->P, op->nx, op->ny, op->nz, op->bx, op->by, op->bz, op->d_G6blk, op->d_D, op->dm,
                                   op->coeff, d_x, d_y, s);
@@ -451,6 +456,51 @@ int wf_op_apply(wf_op* op, const double* d_x, double* d_y, void* stream)
   }
   set_error("wf_op_apply: corrupt handle");
   return WF_ERR_INVALID;
+}
+
+int wf_op_set_ghost_faces(wf_op* op, int ghost_x0, int ghost_y0, int ghost_z0)
+{
+  WF_REQUIRE(op != nullptr, "wf_op_set_ghost_faces: null handle");
+  if (!(op->structured && op->kind == WF_OP_STIFFNESS && op->march)) {
+    set_error("wf_op_set_ghost_faces: only the marching box stiffness operator splits into interior/interface parts");
+    return WF_ERR_UNSUPPORTED;
+  }
+  const int nbx = (op->nx + op->bx - 1) / op->bx, nby = (op->ny + op->by - 1) / op->by;
+  const int ncols = nbx * nby, nseg = (op->nz + op->lz - 1) / op->lz;
+  std::vector<int32_t> items[2];
+  for (int seg = 0; seg < nseg; ++seg)
+    for (int col = 0; col < ncols; ++col) {
+      const int Bx = col % nbx, By = col / nbx;
+      // a work item is "interface" when it reads a ghost plane of x / adds into a ghost plane of y
+      const bool iface = (ghost_x0 && Bx == 0) || (ghost_y0 && By == 0) || (ghost_z0 && seg == 0);
+      items[iface ? 1 : 0].push_back(col + ncols * seg);
+    }
+  for (int k = 0; k < 2; ++k) {
+    (void)hipFree(op->d_items[k]);
+    op->d_items[k] = nullptr;
+    op->nitems[k] = (int)items[k].size();
+    if (op->nitems[k]) {
+      int rc = dev_upload(&op->d_items[k], items[k].data(), items[k].size(), &op->device_bytes);
+      if (rc != WF_OK) return rc;
+    }
+  }
+  op->have_parts = 1;
+  return WF_OK;
+}
+
+int wf_op_apply_part(wf_op* op, const double* d_x, double* d_y, int part, void* stream)
+{
+  WF_REQUIRE(op && d_x && d_y, "wf_op_apply_part: null argument");
+  if (part == WF_PART_ALL) return wf_op_apply(op, d_x, d_y, stream);
+  WF_REQUIRE(part == WF_PART_INTERIOR || part == WF_PART_INTERFACE, "wf_op_apply_part: unknown part");
+  if (!op->have_parts) {
+    set_error("wf_op_apply_part: call wf_op_set_ghost_faces first");
+    return WF_ERR_INVALID;
+  }
+  const int k = part == WF_PART_INTERIOR ? 0 : 1;
+  if (op->nitems[k] == 0) return WF_OK;
+  return launch_stiffness_march(op->P, op->march_variant, op->nx, op->ny, op->nz, op->lz, op->d_G6blk, op->d_D, op->dm,
+                                op->coeff, d_x, d_y, op->d_items[k], op->nitems[k], (hipStream_t)stream);
 }
 
 int wf_op_info(const wf_op* op, wf_op_info_t* info)
@@ -471,6 +521,8 @@ int wf_op_info(const wf_op* op, wf_op_info_t* info)
   else
     info->alg_bytes = (double)op->ncells * (8.0 * op->nq + 4.0 * op->nd) + 16.0 * op->ndofs;
   info->device_bytes = op->device_bytes;
+  info->items_interior = op->nitems[0];
+  info->items_interface = op->nitems[1];
   return WF_OK;
 }
 

@@ -63,7 +63,7 @@ int launch_stiffness_box(int P, int nx, int ny, int nz, int bx, int by, int bz, 
 bool march_variant(int P, int variant, int* bx, int* by);
 int launch_stiffness_march(int P, int variant, int nx, int ny, int nz, int lz, const double* d_G6blk,
                            const double* d_D, const DMat& dm, double coeff, const double* d_x, double* d_y,
-                           hipStream_t s);
+                           const int32_t* d_items, int nitems, hipStream_t s);
 int launch_mass_lumped(int64_t nentries, const int32_t* d_dofmap, const double* d_detJ, const double* d_x,
                        double* d_y, hipStream_t s);
 int launch_mass_dense(int P, int nq1, int ncells, const int32_t* d_dofmap, const double* d_phi1,

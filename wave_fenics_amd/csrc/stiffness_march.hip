@@ -32,7 +32,8 @@ __global__ __launch_bounds__(256, (P <= 4 ? 2 : 1)) void k_stiffness_march(int n
                                                             const double2* __restrict__ G6blk,
                                                             const double* __restrict__ dD, DMat dm,
                                                             double coeff, const double* __restrict__ x,
-                                                            double* __restrict__ y, int ablate)
+                                                            double* __restrict__ y,
+                                                            const int32_t* __restrict__ items, int ablate)
 {
   constexpr int n = P + 1, n2 = n * n, nd = n * n2;
   constexpr int CB = BX * BY, NT = CB * n2;
@@ -51,7 +52,10 @@ __global__ __launch_bounds__(256, (P <= 4 ? 2 : 1)) void k_stiffness_march(int n
   const int t = threadIdx.x;
   const int nbx = (nx + BX - 1) / BX, nby = (ny + BY - 1) / BY;
   const int ncols = nbx * nby;
-  const int col = blockIdx.x % ncols, seg = blockIdx.x / ncols;
+  // work item = (column, z segment); an optional item list selects a subset (the
+  // interior / interface split used to overlap the ghost exchange)
+  const int item = items ? items[blockIdx.x] : (int)blockIdx.x;
+  const int col = item % ncols, seg = item / ncols;
   const int Bx = col % nbx, By = col / nbx;
   const int z0 = seg * lz, z1 = min(nz, z0 + lz);
   const bool active = t < NT;
@@ -226,12 +230,15 @@ static int march_ablate()
 
 template <int P, int BX, int BY>
 static int launch_march_t(int nx, int ny, int nz, int lz, const double* d_G6blk, const double* d_D,
-                          const DMat& dm, double coeff, const double* d_x, double* d_y, hipStream_t s)
+                          const DMat& dm, double coeff, const double* d_x, double* d_y, const int32_t* d_items,
+                          int nitems, hipStream_t s)
 {
   const int ncols = ((nx + BX - 1) / BX) * ((ny + BY - 1) / BY);
   const int nseg = (nz + lz - 1) / lz;
-  hipLaunchKernelGGL((k_stiffness_march<P, BX, BY>), dim3((unsigned)(ncols * nseg)), dim3(256), 0, s, nx, ny, nz,
-                     lz, reinterpret_cast<const double2*>(d_G6blk), d_D, dm, coeff, d_x, d_y, march_ablate());
+  const int nwg = d_items ? nitems : ncols * nseg;
+  if (nwg == 0) return WF_OK;
+  hipLaunchKernelGGL((k_stiffness_march<P, BX, BY>), dim3((unsigned)nwg), dim3(256), 0, s, nx, ny, nz, lz,
+                     reinterpret_cast<const double2*>(d_G6blk), d_D, dm, coeff, d_x, d_y, d_items, march_ablate());
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     set_error(std::string("stiffness_march launch failed: ") + hipGetErrorString(e));
@@ -260,11 +267,11 @@ bool march_variant(int P, int variant, int* bx, int* by)
 }
 
 #define WF_MARCH_CASE(PP, V, BXX, BYY) \
-  if (P == PP && variant == V) return launch_march_t<PP, BXX, BYY>(nx, ny, nz, lz, d_G6blk, d_D, dm, coeff, d_x, d_y, s);
+  if (P == PP && variant == V) return launch_march_t<PP, BXX, BYY>(nx, ny, nz, lz, d_G6blk, d_D, dm, coeff, d_x, d_y, d_items, nitems, s);
 
 int launch_stiffness_march(int P, int variant, int nx, int ny, int nz, int lz, const double* d_G6blk,
                            const double* d_D, const DMat& dm, double coeff, const double* d_x, double* d_y,
-                           hipStream_t s)
+                           const int32_t* d_items, int nitems, hipStream_t s)
 {
   if ((size_t)nx * ny * nz == 0) return WF_OK;
   WF_MARCH_CASE(1, 0, 8, 8) WF_MARCH_CASE(1, 1, 4, 4) WF_MARCH_CASE(1, 2, 8, 4)

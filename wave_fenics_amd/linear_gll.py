@@ -117,6 +117,10 @@ class LinearGLLOpt:
         self.idx2, self.mG2 = td(i2, torch.int32), td(m2, torch.float64)
         # LinearGLL.hpp:120-127
         self.stiff_op = StiffnessOperator(V, self.k_, {"c0": self.c0_}, structured=structured)
+        # domain-decomposed run: interior cells overlap the forward ghost update
+        self._split = False
+        if self.updater is not None:
+            self._split = self.stiff_op.set_ghost_faces(*[bool(v) for v in self.updater.part.owned_lo])
         self.stiff_op(self.u_n, self.b)
         if self.updater is not None:
             self.updater.scatter_rev(self.b)
@@ -137,14 +141,28 @@ class LinearGLLOpt:
         else:
             self.window_ = 1.0
         self.g_ = self.window_ * self.p0_ * self.w0_ / self.c0_ * math.cos(self.w0_ * t)
-        if self.updater is not None:
-            self.updater.scatter_fwd(u)
-        la.copy(u, self.u_n)
-        if self.updater is not None:
+        if self._split:
+            # same operations as below, reordered so that the cells that read no ghost
+            # value run while the halo of u is in flight (update_fwd_begin/_end,
+            # VectorUpdater.hpp:106-143)
+            from ._lib import WF_PART_INTERFACE, WF_PART_INTERIOR
+            la.fill(self.b, 0.0)
+            self.updater.update_fwd_begin(u)
+            self.stiff_op.apply_part(u, self.b, WF_PART_INTERIOR)
+            self.updater.update_fwd_end(u)
+            la.copy(u, self.u_n)
             self.updater.scatter_fwd(v)
-        la.copy(v, self.v_n)
-        la.fill(self.b, 0.0)
-        self.stiff_op(self.u_n, self.b)
+            la.copy(v, self.v_n)
+            self.stiff_op.apply_part(self.u_n, self.b, WF_PART_INTERFACE)
+        else:
+            if self.updater is not None:
+                self.updater.scatter_fwd(u)
+            la.copy(u, self.u_n)
+            if self.updater is not None:
+                self.updater.scatter_fwd(v)
+            la.copy(v, self.v_n)
+            la.fill(self.b, 0.0)
+            self.stiff_op(self.u_n, self.b)
         la.boundary_apply(self.idx1, self.mG1, self.c0_ ** 2 * self.g_,
                           self.idx2, self.mG2, -self.c0_, self.v_n, self.b)
         if self.updater is not None:

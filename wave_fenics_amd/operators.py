@@ -131,6 +131,32 @@ class _Operator:
 
     __call__ = apply
 
+    def set_ghost_faces(self, gx: bool, gy: bool, gz: bool) -> bool:
+        """Declare which lower lattice planes are ghost planes (domain
+        decomposition).  Returns False when this operator cannot be split (generic
+        dofmap kernels): the caller then uses the unsplit sequence."""
+        rc = lib().wf_op_set_ghost_faces(self._h, int(gx), int(gy), int(gz))
+        if rc == -2:
+            return False
+        check(rc)
+        self._info()
+        return True
+
+    def part_fraction(self, part: int) -> float:
+        """Share of the operator's work items in `part` (after set_ghost_faces)."""
+        tot = self.info.items_interior + self.info.items_interface
+        if tot == 0:
+            return 1.0
+        return (self.info.items_interior if part == 1 else self.info.items_interface) / tot
+
+    def apply_part(self, x, y, part: int, stream: int | None = None):
+        """y += A_part x, part in (WF_PART_INTERIOR, WF_PART_INTERFACE):
+        interior cells read no ghost value of x."""
+        _check_vec(x, self.info.ndofs, "x")
+        _check_vec(y, self.info.ndofs, "y")
+        s = _stream(x) if stream is None else stream
+        check(lib().wf_op_apply_part(self._h, _ptr(x), _ptr(y), part, s))
+
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
             lib().wf_op_destroy(self._h)
