@@ -172,6 +172,15 @@ int wf_pointwise_div(int64_t n, const double* d_b, const double* d_m, double* d_
 int wf_pointwise_mult_add(int64_t n, const double* d_m, const double* d_x, double* d_y, void* stream); /* y += m .* x */
 int wf_dot(int64_t n, const double* d_x, const double* d_y, double* d_result, void* stream);           /* la.hpp:87 inner_product; result on device */
 
+/* Fused vector algebra between two stiffness applies of the RK4 loop
+ * (common/LinearGLL.hpp:182-191, :260, :264-265 and the next stage's :250-254):
+ *   kv = b/m; ku = vn; u = ku*bdt + u_read; v = kv*bdt + v_read;
+ *   if has_next: un = ku*adt_next + u0; vn_next = kv*adt_next + v0; b = 0.
+ * u_read/v_read may alias u/v; vn_next must not alias vn. */
+int wf_rk4_stage(int64_t n, double bdt, double adt_next, int has_next, double* d_b, const double* d_m,
+                 const double* d_vn, const double* d_u_read, const double* d_v_read, double* d_u, double* d_v,
+                 const double* d_u0, const double* d_v0, double* d_un, double* d_vn_next, void* stream);
+
 /* ---- a7: boundary operator (diagonal form of forms.ufl:19-24) -------------
  * b[idx1[i]] += s1 * m1[i];  b[idx2[i]] += s2 * m2[i] * v[idx2[i]].
  * LinearGLL.hpp:175 with s1 = c0^2 g(t), s2 = -c0. */

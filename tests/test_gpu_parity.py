@@ -407,6 +407,14 @@ def test_rk4_cfg1_vs_oracle(gpu, oracle):
         assert steps == 100
         assert relerr(eqn.u_n.cpu().numpy(), ref.u_n) <= 1e-9
         assert relerr(eqn.v_n.cpu().numpy(), ref.v_n) <= 1e-9
+        # fused stage pipeline (wf_rk4_stage): same expressions, one pass between applies
+        fus = LinearGLLOpt(V, p, 1500.0, 0.5e6, 6e4, structured=structured)
+        fus.init()
+        t, steps = fus.rk4_fused(0.0, 100 * dt - 1e-13, dt)
+        assert steps == 100
+        assert relerr(fus.u_n.cpu().numpy(), ref.u_n) <= 1e-9
+        assert relerr(fus.v_n.cpu().numpy(), ref.v_n) <= 1e-9
+        assert relerr(fus.u_n.cpu().numpy(), eqn.u_n.cpu().numpy()) <= 1e-11
 
 
 def _dist_gpu_worker(rank, world, port, n, p, q):
@@ -458,6 +466,11 @@ def _dist_gpu_worker(rank, world, port, n, p, q):
         u = eqn.u_n.cpu().numpy()
         errs["rk4_u"] = float(np.abs(u - ref.u_n[l2g]).max() / np.abs(ref.u_n).max())    # ghosts included (final scatter_fwd)
         errs["rk4_v"] = float(np.abs(eqn.v_n.cpu().numpy() - ref.v_n[l2g]).max() / np.abs(ref.v_n).max())
+        fus = LinearGLLOpt(part.V, p, 1500.0, 0.5e6, 6e4, updater=vu, tags=boundary_tags(part), device=dev)
+        fus.init()
+        fus.rk4_fused(0.0, 20 * dt - 1e-13, dt)
+        errs["rk4f_u"] = float(np.abs(fus.u_n.cpu().numpy() - ref.u_n[l2g]).max() / np.abs(ref.u_n).max())
+        errs["rk4f_v"] = float(np.abs(fus.v_n.cpu().numpy() - ref.v_n[l2g]).max() / np.abs(ref.v_n).max())
         dist.barrier()
         dist.destroy_process_group()
         q.put((rank, errs, None))
@@ -489,3 +502,4 @@ def test_distributed_on_one_gpu(gpu, oracle, world, n, p):
         assert tb is None, f"rank {rank} failed:\n{tb}"
         assert errs["K1"] <= 1e-11 and errs["K0"] <= 1e-11, errs
         assert errs["rk4_u"] <= 1e-9 and errs["rk4_v"] <= 1e-9, errs
+        assert errs["rk4f_u"] <= 1e-9 and errs["rk4f_v"] <= 1e-9, errs

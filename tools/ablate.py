@@ -51,7 +51,7 @@ def main():
     alg = ops["generic"].alg_bytes()
     masks = [int(v) for v in os.environ.get("MASKS", "0,1,2,4,8,3,5,7,15").split(",")]
     print(f"P{p} N{n} ndofs {V.ndofs} alg_bytes {alg/1e6:.1f} MB")
-    print("kernel".ljust(16) + "".join(f"{m:>9d}" for m in masks))
+    print("kernel".ljust(20) + "".join(f"{m:>9d}" for m in masks))
     for name, op in ops.items():
         row = []
         for m in masks:
@@ -59,7 +59,7 @@ def main():
             med, mn = time_op(op, x, y)
             row.append(med)
         os.environ["WF_ABLATE"] = "0"
-        print(name.ljust(16) + "".join(f"{t:9.3f}" for t in row), flush=True)
+        print(name.ljust(20) + "".join(f"{t:9.3f}" for t in row), flush=True)
     # plain HBM copy reference on the same device (same byte count as alg_bytes)
     nb = int(alg // 16)
     a = torch.empty(nb, dtype=torch.float64, device=dev)

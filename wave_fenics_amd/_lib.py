@@ -74,6 +74,7 @@ SIGNATURES = {
     "wf_pointwise_div": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "wf_pointwise_mult_add": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "wf_dot": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "wf_rk4_stage": (c_int, [c_int64, c_double, c_double, c_int] + [c_void_p] * 12),
     "wf_boundary_apply": (c_int, [c_int32, c_void_p, c_void_p, c_double, c_int32, c_void_p, c_void_p, c_double,
                                   c_void_p, c_void_p, c_void_p]),
 }

@@ -108,6 +108,33 @@ __global__ void k_boundary(int32_t n1, const int32_t* __restrict__ idx1, const d
   }
 }
 
+// Fused tail of one RK4 stage (common/LinearGLL.hpp:182-191 divide, :260 f0,
+// :264-265 solution update) plus the head of the next stage (:250-254), so that
+// the vector algebra between two stiffness applies is ONE pass:
+//   kv = b / m ; ku = vn
+//   u_ = ku*(dt*b_i) + u_read ; v_ = kv*(dt*b_i) + v_read
+//   un = ku*(dt*a_next) + u0  ; vn_next = kv*(dt*a_next) + v0 ; b = 0      (if has_next)
+// 96 B/dof instead of the 208 B/dof of the reference's separate copy/axpy/fill/
+// transform passes.  u_read/v_read may alias u_/v_ (stages 1..3) or be u0/v0
+// (stage 0, where u_ == u0 by construction).
+__global__ void k_rk4_stage(int64_t n, double bdt, double adt_next, int has_next, double* __restrict__ b,
+                            const double* __restrict__ m, const double* vn, const double* u_read,
+                            const double* v_read, double* u_, double* v_, const double* __restrict__ u0,
+                            const double* __restrict__ v0, double* un, double* vn_next)
+{
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (int64_t)gridDim.x * blockDim.x) {
+    const double kv = b[g] / m[g];
+    const double ku = vn[g];
+    u_[g] = ku * bdt + u_read[g];
+    v_[g] = kv * bdt + v_read[g];
+    if (has_next) {
+      un[g] = ku * adt_next + u0[g];
+      vn_next[g] = kv * adt_next + v0[g];
+      b[g] = 0.0;
+    }
+  }
+}
+
 }  // namespace wf
 
 using namespace wf;
@@ -197,6 +224,20 @@ int wf_dot(int64_t n, const double* d_x, const double* d_y, double* d_result, vo
   WF_LAUNCH_CHECK();
   return WF_OK;
 }
+int wf_rk4_stage(int64_t n, double bdt, double adt_next, int has_next, double* d_b, const double* d_m,
+                 const double* d_vn, const double* d_u_read, const double* d_v_read, double* d_u, double* d_v,
+                 const double* d_u0, const double* d_v0, double* d_un, double* d_vn_next, void* stream)
+{
+  if (n <= 0) return WF_OK;
+  WF_REQUIRE(d_b && d_m && d_vn && d_u_read && d_v_read && d_u && d_v, "wf_rk4_stage: null vector");
+  WF_REQUIRE(!has_next || (d_u0 && d_v0 && d_un && d_vn_next), "wf_rk4_stage: next-stage vectors missing");
+  WF_REQUIRE(!has_next || d_vn_next != d_vn, "wf_rk4_stage: vn_next must not alias vn");
+  hipLaunchKernelGGL(k_rk4_stage, dim3(capped_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, n, bdt, adt_next,
+                     has_next, d_b, d_m, d_vn, d_u_read, d_v_read, d_u, d_v, d_u0, d_v0, d_un, d_vn_next);
+  WF_LAUNCH_CHECK();
+  return WF_OK;
+}
+
 int wf_boundary_apply(int32_t n1, const int32_t* d_idx1, const double* d_m1, double s1, int32_t n2,
                       const int32_t* d_idx2, const double* d_m2, double s2, const double* d_v, double* d_b,
                       void* stream)

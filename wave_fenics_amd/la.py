@@ -56,3 +56,14 @@ def boundary_apply(idx1, m1, s1: float, idx2, m2, s2: float, v, b):
     check(lib().wf_boundary_apply(n1, _ptr(idx1) if n1 else 0, _ptr(m1) if n1 else 0, float(s1),
                                   n2, _ptr(idx2) if n2 else 0, _ptr(m2) if n2 else 0, float(s2),
                                   _ptr(v), _ptr(b), _stream(b)))
+
+
+def rk4_stage(b, m, vn, u_read, v_read, u, v, bdt: float, adt_next: float = 0.0, u0=None, v0=None, un=None,
+              vn_next=None):
+    """Fused stage tail + next stage head (wf_rk4_stage)."""
+    has_next = un is not None
+    z = 0
+    check(lib().wf_rk4_stage(b.numel(), float(bdt), float(adt_next), int(has_next), _ptr(b), _ptr(m), _ptr(vn),
+                             _ptr(u_read), _ptr(v_read), _ptr(u), _ptr(v),
+                             _ptr(u0) if has_next else z, _ptr(v0) if has_next else z,
+                             _ptr(un) if has_next else z, _ptr(vn_next) if has_next else z, _stream(b)))

@@ -209,6 +209,81 @@ class LinearGLLOpt:
         return t, step
 
 
+def _rk4_fused(self, startTime: float, finalTime: float, timeStep: float, max_steps: int | None = None):
+    """The same RK4 integration as rk4() (LinearGLL.hpp:198-287) with the vector
+    algebra between two stiffness applies fused into one pass (wf_rk4_stage) and
+    the stage-0 copies removed by pointer rotation: per stage
+    K (116 B/dof at P4) + 96 B/dof instead of K + 208 B/dof.  Same arithmetic
+    expressions as the unfused loop."""
+    from ._lib import WF_PART_INTERFACE, WF_PART_INTERIOR
+    t, tf, dt = startTime, finalTime, timeStep
+    step = 0
+    new = lambda: torch.zeros_like(self.u_n)
+    u0, v0 = self.u_n.clone(), self.v_n.clone()      # solution at the start of the step
+    u_, v_ = new(), new()                              # running solution of the step
+    un, vn_a, vn_b = new(), new(), new()
+    b, m = self.b, self.m
+    a_runge = [0.0, 0.5, 0.5, 1.0]
+    b_runge = [1.0 / 6.0, 1.0 / 3.0, 1.0 / 3.0, 1.0 / 6.0]
+    c_runge = [0.0, 0.5, 0.5, 1.0]
+    upd = self.updater
+
+    def rhs(tn, x_u, x_v):
+        """b = K x_u + boundary(x_v) (+ reverse ghost update); b is zero on entry."""
+        if tn < self.T_ * self.alpha_:
+            window = 0.5 * (1.0 - math.cos(self.freq0_ * math.pi * tn / self.alpha_))
+        else:
+            window = 1.0
+        g = window * self.p0_ * self.w0_ / self.c0_ * math.cos(self.w0_ * tn)
+        if self._split:
+            upd.update_fwd_begin(x_u)
+            self.stiff_op.apply_part(x_u, b, WF_PART_INTERIOR)
+            upd.update_fwd_end(x_u)
+            upd.scatter_fwd(x_v)
+            self.stiff_op.apply_part(x_u, b, WF_PART_INTERFACE)
+        else:
+            if upd is not None:
+                upd.scatter_fwd(x_u)
+                upd.scatter_fwd(x_v)
+            self.stiff_op(x_u, b)
+        la.boundary_apply(self.idx1, self.mG1, self.c0_ ** 2 * g, self.idx2, self.mG2, -self.c0_, x_v, b)
+        if upd is not None:
+            upd.scatter_rev(b)
+
+    la.fill(b, 0.0)
+    while t < tf:
+        dt = min(dt, tf - t)
+        # stage 0: un = u0, vn = v0 (a_0 = 0), read straight from u0 / v0
+        x_u, x_v = u0, v0
+        vn_next = vn_a
+        for i in range(4):
+            rhs(t + c_runge[i] * dt, x_u, x_v)
+            last = i == 3
+            ur, vr = (u0, v0) if i == 0 else (u_, v_)
+            if not last:
+                la.rk4_stage(b, m, x_v, ur, vr, u_, v_, dt * b_runge[i], dt * a_runge[i + 1], u0, v0, un, vn_next)
+                x_u, x_v = un, vn_next
+                vn_next = vn_b if vn_next is vn_a else vn_a
+            else:
+                la.rk4_stage(b, m, x_v, ur, vr, u_, v_, dt * b_runge[i])
+                la.fill(b, 0.0)
+        u0, u_ = u_, u0          # the new solution becomes the next step's u0
+        v0, v_ = v_, v0
+        t += dt
+        step += 1
+        if max_steps is not None and step >= max_steps:
+            break
+    la.copy(u0, self.u_n)
+    la.copy(v0, self.v_n)
+    if upd is not None:
+        upd.scatter_fwd(self.u_n)
+        upd.scatter_fwd(self.v_n)
+    return t, step
+
+
+LinearGLLOpt.rk4_fused = _rk4_fused
+
+
 def cfl_time_step(mesh, degree: int, c0: float, freq: float, CFL: float = 0.5):
     """demo/cpu_planar3d/main.cpp:48-66."""
     xc = mesh.x[mesh.geom_dofmap]
