@@ -397,75 +397,87 @@ __global__ void k_mass_lumped(int64_t nentries, const int32_t* __restrict__ dofm
 // --------------------------------------------------------------------------
 // dense mass Phi^T D Phi with a tensor-product rule, sum-factorised:
 // replaces common/cuda/mass_kernel.cu:5-46 and the DGEMM pair of
-// demo/gpu_operator/main.cpp:149-155.  One workgroup per cell; the tall-skinny
-// (k >> m ~ n) basis products become three 1-D contractions through LDS.
-// phi1: [nq1][n] row-major.
+// demo/gpu_operator/main.cpp:149-155 / demo/gpu_tsmm (k >> m ~ n).  A workgroup
+// processes CB cells at once (P2: 32 cells) so that all 256 lanes work in each of
+// the six 1-D contraction passes; the passes ping-pong between two LDS tiles.
+// phi1: [m][n] row-major (m 1-D quadrature points, n = P+1 1-D nodes).
 // --------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_mass_dense(int n, int m, int ncells,
+__global__ __launch_bounds__(256) void k_mass_dense(int n, int m, int CB, int ncells,
                                                     const int32_t* __restrict__ dofmap,
                                                     const double* __restrict__ phi1,
                                                     const double* __restrict__ detJ,
                                                     const double* __restrict__ x, double* __restrict__ y)
 {
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  const int mx = max(n, m);
-  double* A = smem;                       // ping  [mx^3]
-  double* B = A + mx * mx * mx;           // pong  [mx^3]
-  double* sphi = B + mx * mx * mx;        // [m][n]
+  const int mx = max(n, m), mx3 = mx * mx * mx;
+  double* A = smem;                  // ping  [CB][mx^3]
+  double* B = A + CB * mx3;          // pong  [CB][mx^3]
+  double* sphi = B + CB * mx3;       // [m][n]
   const int t = threadIdx.x;
   const int nd = n * n * n, nq = m * m * m;
   for (int p = t; p < m * n; p += 256) sphi[p] = phi1[p];
-  for (int c = blockIdx.x; c < ncells; c += gridDim.x) {
+  const int nbatch = (ncells + CB - 1) / CB;
+  for (int batch = blockIdx.x; batch < nbatch; batch += gridDim.x) {
+    const int c0 = batch * CB;
+    const int nc = min(CB, ncells - c0);
     __syncthreads();
-    for (int p = t; p < nd; p += 256) A[p] = x[dofmap[(size_t)c * nd + p]];
-    __syncthreads();
-    // forward: u[k][j][i] -> q index, one direction at a time
-    // x: B[k][j][qi] = sum_i phi[qi][i] A[k][j][i]     (n*n*m)
-    for (int p = t; p < n * n * m; p += 256) {
-      const int qi = p % m, kj = p / m;
-      double s = 0.0;
-      for (int a = 0; a < n; ++a) s += sphi[qi * n + a] * A[kj * n + a];
-      B[p] = s;
+    for (int p = t; p < nc * nd; p += 256) {
+      const int c = p / nd, l = p - c * nd;
+      A[c * mx3 + l] = x[dofmap[(size_t)c0 * nd + p]];
     }
     __syncthreads();
-    // y: A[k][qj][qi] = sum_j phi[qj][j] B[k][j][qi]   (n*m*m)
-    for (int p = t; p < n * m * m; p += 256) {
-      const int qi = p % m, qj = (p / m) % m, k = p / (m * m);
+    // forward x: B[c][k][j][qi] = sum_i phi[qi][i] A[c][k][j][i]
+    for (int p = t; p < nc * n * n * m; p += 256) {
+      const int c = p / (n * n * m), r = p - c * (n * n * m);
+      const int qi = r % m, kj = r / m;
       double s = 0.0;
-      for (int a = 0; a < n; ++a) s += sphi[qj * n + a] * B[(k * n + a) * m + qi];
-      A[p] = s;
+      for (int a = 0; a < n; ++a) s += sphi[qi * n + a] * A[c * mx3 + kj * n + a];
+      B[c * mx3 + r] = s;
     }
     __syncthreads();
-    // z + D: B[qk][qj][qi] = detJ * sum_k phi[qk][k] A[k][qj][qi]   (m^3)
-    for (int p = t; p < nq; p += 256) {
-      const int qji = p % (m * m), qk = p / (m * m);
+    // forward y: A[c][k][qj][qi] = sum_j phi[qj][j] B[c][k][j][qi]
+    for (int p = t; p < nc * n * m * m; p += 256) {
+      const int c = p / (n * m * m), r = p - c * (n * m * m);
+      const int qi = r % m, qj = (r / m) % m, k = r / (m * m);
       double s = 0.0;
-      for (int a = 0; a < n; ++a) s += sphi[qk * n + a] * A[a * m * m + qji];
-      B[p] = s * detJ[(size_t)c * nq + p];
+      for (int a = 0; a < n; ++a) s += sphi[qj * n + a] * B[c * mx3 + (k * n + a) * m + qi];
+      A[c * mx3 + r] = s;
     }
     __syncthreads();
-    // backward z: A[k][qj][qi] = sum_qk phi[qk][k] B[qk][qj][qi]
-    for (int p = t; p < n * m * m; p += 256) {
-      const int qji = p % (m * m), k = p / (m * m);
+    // forward z and D: B[c][qk][qj][qi] = detJ * sum_k phi[qk][k] A[c][k][qj][qi]
+    for (int p = t; p < nc * nq; p += 256) {
+      const int c = p / nq, r = p - c * nq;
+      const int qji = r % (m * m), qk = r / (m * m);
       double s = 0.0;
-      for (int a = 0; a < m; ++a) s += sphi[a * n + k] * B[a * m * m + qji];
-      A[p] = s;
+      for (int a = 0; a < n; ++a) s += sphi[qk * n + a] * A[c * mx3 + a * m * m + qji];
+      B[c * mx3 + r] = s * detJ[(size_t)(c0 + c) * nq + r];
     }
     __syncthreads();
-    // backward y: B[k][j][qi] = sum_qj phi[qj][j] A[k][qj][qi]
-    for (int p = t; p < n * n * m; p += 256) {
-      const int qi = p % m, j = (p / m) % n, k = p / (m * n);
+    // backward z: A[c][k][qj][qi] = sum_qk phi[qk][k] B[c][qk][qj][qi]
+    for (int p = t; p < nc * n * m * m; p += 256) {
+      const int c = p / (n * m * m), r = p - c * (n * m * m);
+      const int qji = r % (m * m), k = r / (m * m);
       double s = 0.0;
-      for (int a = 0; a < m; ++a) s += sphi[a * n + j] * A[(k * m + a) * m + qi];
-      B[p] = s;
+      for (int a = 0; a < m; ++a) s += sphi[a * n + k] * B[c * mx3 + a * m * m + qji];
+      A[c * mx3 + r] = s;
     }
     __syncthreads();
-    // backward x + scatter: y[dof] += sum_qi phi[qi][i] B[k][j][qi]
-    for (int p = t; p < nd; p += 256) {
-      const int i = p % n, kj = p / n;
+    // backward y: B[c][k][j][qi] = sum_qj phi[qj][j] A[c][k][qj][qi]
+    for (int p = t; p < nc * n * n * m; p += 256) {
+      const int c = p / (n * n * m), r = p - c * (n * n * m);
+      const int qi = r % m, j = (r / m) % n, k = r / (m * n);
       double s = 0.0;
-      for (int a = 0; a < m; ++a) s += sphi[a * n + i] * B[kj * m + a];
-      unsafeAtomicAdd(&y[dofmap[(size_t)c * nd + p]], s);
+      for (int a = 0; a < m; ++a) s += sphi[a * n + j] * A[c * mx3 + (k * m + a) * m + qi];
+      B[c * mx3 + r] = s;
+    }
+    __syncthreads();
+    // backward x and scatter: y[dof] += sum_qi phi[qi][i] B[c][k][j][qi]
+    for (int p = t; p < nc * nd; p += 256) {
+      const int c = p / nd, l = p - c * nd;
+      const int i = l % n, kj = l / n;
+      double s = 0.0;
+      for (int a = 0; a < m; ++a) s += sphi[a * n + i] * B[c * mx3 + kj * m + a];
+      unsafeAtomicAdd(&y[dofmap[(size_t)c0 * nd + p]], s);
     }
   }
 }
@@ -613,17 +625,20 @@ int launch_mass_dense(int P, int nq1, int ncells, const int32_t* d_dofmap, const
                       const double* d_detJ, const double* d_x, double* d_y, hipStream_t s)
 {
   if (ncells == 0) return WF_OK;
-  const int n = P + 1, mx = n > nq1 ? n : nq1;
-  const size_t lds = (size_t)(2 * mx * mx * mx + nq1 * n) * sizeof(double);
+  const int n = P + 1, mx = n > nq1 ? n : nq1, mx3 = mx * mx * mx;
+  // cells per workgroup: enough that every contraction pass fills 256 lanes, within ~32 KB of LDS
+  int CB = std::max(1, std::min(1400 / mx3, 32));   // measured: P2 >= 8, P4 2..8, P6 4 cells per workgroup
+  if (const char* e = std::getenv("WF_MASS_CB")) CB = std::max(1, std::atoi(e));   // tuning hook
+  const size_t lds = (size_t)(2 * CB * mx3 + nq1 * n) * sizeof(double);
   if (lds > 160 * 1024) {
     set_error("mass_dense: tables do not fit LDS");
     return WF_ERR_UNSUPPORTED;
   }
-  const unsigned nb = (unsigned)std::min<int64_t>(ncells, 256 * 8);
+  const unsigned nb = (unsigned)std::min<int64_t>((ncells + CB - 1) / CB, 256 * 8);
   if (lds > 64 * 1024)
     WF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mass_dense), hipFuncAttributeMaxDynamicSharedMemorySize,
                         (int)lds));
-  hipLaunchKernelGGL(k_mass_dense, dim3(nb), dim3(256), lds, s, n, nq1, ncells, d_dofmap, d_phi1, d_detJ, d_x,
+  hipLaunchKernelGGL(k_mass_dense, dim3(nb), dim3(256), lds, s, n, nq1, CB, ncells, d_dofmap, d_phi1, d_detJ, d_x,
                      d_y);
   WF_LAUNCH_CHECK();
   return WF_OK;
