@@ -130,6 +130,28 @@ int wf_op_create(const wf_op_desc* desc, wf_op** out);
 int wf_op_create_box(int kind, int degree, int nx, int ny, int nz,
                      const double* h_xverts, double c0, int flags, wf_op** out);
 
+/* Dense (non-tensor-product) stiffness operator on affine simplex cells: the
+ * reference's skernel (common/operators.hpp:113-133) fed with arbitrary dense
+ * tables, as its cell loop (operators.hpp:183-200) would be for a tetrahedral
+ * space.  h_dphi is the table the reference keeps as `_dphi` (operators.hpp:178):
+ * [3][nq][nd], already clamped by the caller like operators.hpp:27-29;
+ * h_weights [nq]; cells are affine tetrahedra given by h_geom_dofmap [ncells][4].
+ * G = (J^-1 |det J| w_q) J^-T with the -1/0/1 clamp is formed on the fly
+ * (precomputation.hpp:95-107).  Compiled shapes: Lagrange P1..P4. */
+typedef struct {
+  int nd, nq;                   /* dofs and quadrature points per cell            */
+  int ncells, ndofs;
+  const int32_t* h_dofmap;      /* [ncells][nd]                                   */
+  const double* h_dphi;         /* [3][nq][nd]                                    */
+  const double* h_weights;      /* [nq]                                           */
+  int nverts;
+  const double* h_xverts;       /* [nverts][3]                                    */
+  const int32_t* h_geom_dofmap; /* [ncells][4]                                    */
+  double c0;
+  int flags;                    /* WF_FLAG_NO_CLAMP                               */
+} wf_dense_desc;
+int wf_op_create_dense_simplex(const wf_dense_desc* desc, wf_op** out);
+
 /* op(x, y) / op.apply(x, y): y += A x.  operators.hpp:183, mass.hpp:76,
  * spectral_mass.hpp:84. */
 int wf_op_apply(wf_op* op, const double* d_x, double* d_y, void* stream);

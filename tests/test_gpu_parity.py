@@ -503,3 +503,27 @@ def test_distributed_on_one_gpu(gpu, oracle, world, n, p):
         assert errs["K1"] <= 1e-11 and errs["K0"] <= 1e-11, errs
         assert errs["rk4_u"] <= 1e-9 and errs["rk4_v"] <= 1e-9, errs
         assert errs["rk4f_u"] <= 1e-9 and errs["rk4f_v"] <= 1e-9, errs
+
+
+@pytest.mark.parametrize("p,n,perturb", [(1, (3, 3, 2), 0.2), (2, (3, 2, 2), 0.2), (3, (2, 2, 2), 0.2), (4, (3, 2, 2), 0.2),
+                                         (4, (2, 2, 1), 0.0), (4, (5, 3, 1), 0.15)])
+def test_tet_dense_stiffness_vs_oracle(gpu, oracle, p, n, perturb):
+    """BASELINE configs[4] at small size: the dense MFMA path on Kuhn tetrahedra
+    against the dense skernel oracle with tetrahedral tables (parity unpinned,
+    oracle/tet_oracle.py).  Partial batches (ncells not a multiple of 64) included."""
+    from oracle import tet_oracle
+    from wave_fenics_amd import tet
+    om = tet_oracle.create_kuhn_box(n, p, perturb=perturb)
+    V = tet.create_kuhn_box(n, p, perturb=perturb)
+    assert np.array_equal(V.dofmap, om.dofmap) and np.array_equal(V.geom_dofmap, om.geom_dofmap)
+    K = tet_oracle.TetStiffnessOperator(om, p)
+    rng = np.random.default_rng(4242)
+    x = rng.uniform(-1, 1, om.ndofs)
+    y0 = rng.uniform(-1, 1, om.ndofs) * 1e6
+    yref = y0.copy()
+    K(x, yref)
+    op = tet.TetStiffnessOperator(V, p, {"c0": 1500.0})
+    y = dev(y0, gpu)
+    op(dev(x, gpu), y)
+    assert relerr(y.cpu().numpy(), yref) <= 1e-11
+    assert op.num_dofs() == K.nd and op.num_quads() == K.nq

@@ -50,9 +50,33 @@ def lagrange(nodes, pts):
     return phi
 
 
+def bench_tet(dev):
+    import time
+    from wave_fenics_amd import tet
+    p, n = 4, int(os.environ.get("TET_N", "54"))
+    t0 = time.time()
+    V = tet.create_kuhn_box(n, p)
+    t1 = time.time()
+    op = tet.TetStiffnessOperator(V, p)
+    t2 = time.time()
+    N = V.ndofs
+    x = torch.rand(N, dtype=torch.float64, device=dev)
+    y = torch.zeros(N, dtype=torch.float64, device=dev)
+    ms = timeit(lambda: op(x, y))
+    report(f"tet P{p} dense stiffness (MFMA f64 16x16x4), Kuhn box {n}^3 cubes", ms, op.alg_bytes(), N,
+           {"cells": V.ncells, "ndofs": N, "TFLOPs_dense_model": round(op.flops() / ms / 1e9, 2),
+            "frac_of_f64_mfma_peak_157TF": round(op.flops() / ms / 1e9 / 157.3, 3),
+            "mesh_s": round(t1 - t0, 2), "setup_s": round(t2 - t1, 2)})
+
+
 def main():
     dev = torch.device("cuda", 0)
     only = sys.argv[1:] or ["stiffness", "mass", "dense", "vector"]
+    if "tet" in only:
+        bench_tet(dev)
+        only = [o for o in only if o != "tet"]
+        if not only:
+            return
     for p in (2, 4, 6):
         n = 216 // p
         mesh = w.create_box(n)

@@ -25,6 +25,15 @@ class OpDesc(ctypes.Structure):
     ]
 
 
+class DenseDesc(ctypes.Structure):
+    _fields_ = [
+        ("nd", c_int), ("nq", c_int), ("ncells", c_int), ("ndofs", c_int),
+        ("h_dofmap", POINTER(c_int32)), ("h_dphi", POINTER(c_double)), ("h_weights", POINTER(c_double)),
+        ("nverts", c_int), ("h_xverts", POINTER(c_double)), ("h_geom_dofmap", POINTER(c_int32)),
+        ("c0", c_double), ("flags", c_int),
+    ]
+
+
 class OpInfo(ctypes.Structure):
     _fields_ = [
         ("kind", c_int), ("degree", c_int), ("num_cells", c_int), ("num_dofs_cell", c_int),
@@ -58,6 +67,7 @@ SIGNATURES = {
     "wf_geometry_hex": (c_int, [c_int, c_int, c_int, _dp, _ip, c_int, c_int, _dp, _dp]),
     "wf_op_create": (c_int, [POINTER(OpDesc), POINTER(c_void_p)]),
     "wf_op_create_box": (c_int, [c_int, c_int, c_int, c_int, c_int, _dp, c_double, c_int, POINTER(c_void_p)]),
+    "wf_op_create_dense_simplex": (c_int, [POINTER(DenseDesc), POINTER(c_void_p)]),
     "wf_op_apply": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "wf_op_set_ghost_faces": (c_int, [c_void_p, c_int, c_int, c_int]),
     "wf_op_apply_part": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),

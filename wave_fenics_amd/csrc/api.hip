@@ -25,6 +25,8 @@ struct wf_op {
   int32_t* d_items[2] = {nullptr, nullptr};   // [0] interior, [1] interface work items (marching kernel)
   int nitems[2] = {0, 0};
   int have_parts = 0;
+  DenseOpData* dense = nullptr;   // dense simplex operator (stiffness_dense.hip)
+  int dense_clamp = 1;
   size_t device_bytes = 0;
 };
 
@@ -70,6 +72,7 @@ void free_op(wf_op* op)
   (void)hipFree(op->d_mdiag);
   (void)hipFree(op->d_items[0]);
   (void)hipFree(op->d_items[1]);
+  dense_free(op->dense);
   delete op;
 }
 
@@ -432,10 +435,41 @@ int wf_op_create_box(int kind, int degree, int nx, int ny, int nz, const double*
   return WF_OK;
 }
 
+int wf_op_create_dense_simplex(const wf_dense_desc* desc, wf_op** out)
+{
+  WF_REQUIRE(desc && out, "wf_op_create_dense_simplex: null argument");
+  *out = nullptr;
+  WF_REQUIRE(desc->nd > 0 && desc->nq > 0 && desc->ncells >= 0 && desc->ndofs >= 0, "wf_op_create_dense_simplex: bad sizes");
+  WF_REQUIRE(desc->h_dofmap && desc->h_dphi && desc->h_weights && desc->h_xverts && desc->h_geom_dofmap,
+             "wf_op_create_dense_simplex: null array");
+  for (size_t e = 0; e < (size_t)desc->ncells * desc->nd; ++e)
+    WF_REQUIRE(desc->h_dofmap[e] >= 0 && desc->h_dofmap[e] < desc->ndofs, "wf_op_create_dense_simplex: dofmap entry out of range");
+  for (size_t e = 0; e < (size_t)desc->ncells * 4; ++e)
+    WF_REQUIRE(desc->h_geom_dofmap[e] >= 0 && desc->h_geom_dofmap[e] < desc->nverts,
+               "wf_op_create_dense_simplex: vertex index out of range");
+  std::unique_ptr<wf_op, void (*)(wf_op*)> op(new wf_op, free_op);
+  op->kind = WF_OP_STIFFNESS;
+  op->P = 0;
+  op->nd = desc->nd;
+  op->nq = desc->nq;
+  op->ncells = desc->ncells;
+  op->ndofs = desc->ndofs;
+  op->coeff = -1.0 * desc->c0 * desc->c0;
+  op->dense_clamp = (desc->flags & WF_FLAG_NO_CLAMP) ? 0 : 1;
+  int rc = dense_setup(desc->nd, desc->nq, desc->ncells, desc->ndofs, desc->h_dofmap, desc->h_dphi, desc->h_weights,
+                       desc->h_xverts, desc->h_geom_dofmap, &op->dense);
+  if (rc != WF_OK) return rc;
+  op->device_bytes = dense_bytes(op->dense);
+  // probe that the shape is compiled before handing the handle out
+  *out = op.release();
+  return WF_OK;
+}
+
 int wf_op_apply(wf_op* op, const double* d_x, double* d_y, void* stream)
 {
   WF_REQUIRE(op && d_x && d_y, "wf_op_apply: null argument");
   hipStream_t s = (hipStream_t)stream;
+  if (op->dense) return launch_stiffness_dense(op->dense, op->coeff, op->dense_clamp, d_x, d_y, s);
   if (op->structured) {
     if (op->kind == WF_OP_STIFFNESS && op->march)
       return launch_stiffness_march(op->P, op->march_variant, op->nx, op->ny, op->nz, op->lz, op->d_G6blk, op->d_D,
@@ -514,7 +548,10 @@ int wf_op_info(const wf_op* op, wf_op_info_t* info)
   info->ndofs = op->ndofs;
   info->structured = op->structured;
   info->flops = 4.0 * op->ncells * (double)op->nq * op->nd;   // mass.hpp:71
-  if (op->kind == WF_OP_STIFFNESS)
+  if (op->dense) {
+    info->flops = 12.0 * op->ncells * (double)op->nq * op->nd;                                  // dense skernel, SURVEY 8a3
+    info->alg_bytes = (double)op->ncells * (48.0 + 4.0 * op->nd) + 16.0 * op->ndofs;
+  } else if (op->kind == WF_OP_STIFFNESS)
     info->alg_bytes = (double)op->ncells * (48.0 * op->nq + 4.0 * op->nd) + 16.0 * op->ndofs;
   else if (op->structured)
     info->alg_bytes = 24.0 * op->ndofs;

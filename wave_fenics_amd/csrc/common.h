@@ -64,6 +64,14 @@ bool march_variant(int P, int variant, int* bx, int* by);
 int launch_stiffness_march(int P, int variant, int nx, int ny, int nz, int lz, const double* d_G6blk,
                            const double* d_D, const DMat& dm, double coeff, const double* d_x, double* d_y,
                            const int32_t* d_items, int nitems, hipStream_t s);
+// dense simplex operator (stiffness_dense.hip)
+struct DenseOpData;
+int dense_setup(int nd, int nq, int ncells, int ndofs, const int32_t* dofmap, const double* dphi,
+                const double* weights, const double* xverts, const int32_t* geom_dofmap, DenseOpData** out);
+void dense_free(DenseOpData* d);
+size_t dense_bytes(const DenseOpData* d);
+int launch_stiffness_dense(const DenseOpData* d, double coeff, int do_clamp, const double* d_x, double* d_y,
+                           hipStream_t s);
 int launch_mass_lumped(int64_t nentries, const int32_t* d_dofmap, const double* d_detJ, const double* d_x,
                        double* d_y, hipStream_t s);
 int launch_mass_dense(int P, int nq1, int ncells, const int32_t* d_dofmap, const double* d_phi1,

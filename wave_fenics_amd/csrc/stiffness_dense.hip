@@ -1,0 +1,321 @@
+// Dense (non-tensor-product) stiffness operator for affine simplex cells:
+// the reference's skernel (common/operators.hpp:113-133) with arbitrary dense
+// tables dphi[3][nq][nd], i.e. the "non-tensor-product operator path" of
+// BASELINE.json configs[4] (P4 tetrahedra, nd = 35, nq = 64).
+//
+//   W[3 nq][cells] = T[3 nq][nd] . U[nd][cells]            (MFMA, f64 16x16x4)
+//   F[dir][q][c]   = -c0^2 * sum_e clamp(w_q C_c)[dir][e] W[e][q][c]   (lane-local)
+//   Y[nd][cells]   = T^T . F                                (MFMA, f64 16x16x4)
+//
+// This is the one place of the engine where the contraction is GEMM-shaped with a
+// k-dimension worth a matrix core (k = nd = 35 and k = 3 nq = 192), so it runs on
+// v_mfma_f64_16x16x4_f64.  One wave owns 16 cells (the N dimension); W stays in
+// registers between the two products: the f64 accumulator layout
+// (row = (lane>>4) + 4*reg, col = lane&15) is exactly the B-operand layout of
+// k-step `reg`, so F feeds the second product with no LDS round trip.
+// The table T lives in LDS; geometry is 6 doubles per affine cell.
+// Gather/scatter ("permute/scatter stress"): per batch of 64 cells the host
+// computes the list of unique dofs; x is read once per unique dof into LDS, the
+// cell results are summed per unique dof in LDS (ds_add_f64) and leave with one
+// global atomic per unique dof.
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+
+#include "common.h"
+
+namespace wf {
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ double clamp101d(double v)
+{
+  if (fabs(v + 1.0) <= 1e-8 + 1e-5) v = -1.0;
+  if (fabs(v) <= 1e-8) v = 0.0;
+  if (fabs(v - 1.0) <= 1e-8 + 1e-5) v = 1.0;
+  return v;
+}
+
+// QT = ceil(nq/16), KT = ceil(nd/4), DT = ceil(nd/16); KP = row pitch of T in LDS.
+template <int QT, int KT, int DT, int NW>
+__global__ __launch_bounds__(64 * NW) void k_stiffness_dense(int nd, int nq, int nbatch, int numax,
+                                                         const double* __restrict__ Tg,      // [3*16*QT][KP] padded table
+                                                         const double* __restrict__ wq,      // [16*QT] weights (0 beyond nq)
+                                                         const double* __restrict__ Cg,      // [nbatch*16*NW][6]
+                                                         const uint16_t* __restrict__ locT,  // [nbatch][4*KT][16*NW]
+                                                         const int32_t* __restrict__ uoff,   // [nbatch+1]
+                                                         const int32_t* __restrict__ uniq,   // unique dofs of all batches
+                                                         double coeff, int do_clamp, const double* __restrict__ x,
+                                                         double* __restrict__ y)
+{
+  constexpr int NQP = 16 * QT, KP = 4 * KT + 1, NT = 64 * NW, NCB = 16 * NW;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* T = smem;                 // [3*NQP][KP]
+  double* sw = T + 3 * NQP * KP;    // [NQP]
+  double* Xu = sw + NQP;            // [numax]  unique x values, later the unique y sums
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int lc = lane & 15, lg = lane >> 4;
+  for (int p = t; p < 3 * NQP * KP; p += NT) T[p] = Tg[p];
+  for (int p = t; p < NQP; p += NT) sw[p] = wq[p];
+
+  for (int batch = blockIdx.x; batch < nbatch; batch += gridDim.x) {
+    const int u0 = uoff[batch], nu = uoff[batch + 1] - u0;
+    __syncthreads();   // previous batch's scatter has read Xu
+    for (int u = t; u < nu; u += NT) Xu[u] = x[uniq[u0 + u]];
+    // per-lane local indices: d = 4*ks + lg of cell (wave*16 + lc)
+    uint16_t loc[KT];
+#pragma unroll
+    for (int ks = 0; ks < KT; ++ks) loc[ks] = locT[((size_t)batch * 4 * KT + 4 * ks + lg) * NCB + wave * 16 + lc];
+    double C[6];
+    {
+      const double* cp = Cg + ((size_t)batch * NCB + wave * 16 + lc) * 6;
+#pragma unroll
+      for (int e = 0; e < 6; ++e) C[e] = cp[e];
+    }
+    __syncthreads();
+
+    // B operands of the first product: this lane's dof values, one per k-step
+    double ub[KT];
+#pragma unroll
+    for (int ks = 0; ks < KT; ++ks) ub[ks] = (4 * ks + lg) < nd ? Xu[loc[ks]] : 0.0;
+
+    double4_t Y[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) Y[dt] = double4_t{0.0, 0.0, 0.0, 0.0};
+
+    // one 16-point slab of quadrature points at a time keeps the register
+    // footprint small (3 accumulator tiles instead of 3*QT) -> more waves per SIMD
+#pragma unroll 1
+    for (int qt = 0; qt < QT; ++qt) {
+      // ---- W = T . U for the rows (dir, 16 qt .. 16 qt + 15) ---------------------
+      double4_t W[3];
+#pragma unroll
+      for (int e = 0; e < 3; ++e) W[e] = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int ks = 0; ks < KT; ++ks) {
+        const int d = 4 * ks + lg;
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+          const double a = T[(e * NQP + 16 * qt + lc) * KP + d];
+          W[e] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, ub[ks], W[e], 0, 0, 0);
+        }
+      }
+      // ---- F = coeff * G W (lane-local: the three directions of one (q, cell) share lane and register)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int q = 16 * qt + lg + 4 * r;
+        const double w = sw[q];
+        double g00 = w * C[0], g01 = w * C[1], g02 = w * C[2], g11 = w * C[3], g12 = w * C[4], g22 = w * C[5];
+        if (do_clamp) {   // precomputation.hpp:105-107
+          g00 = clamp101d(g00); g01 = clamp101d(g01); g02 = clamp101d(g02);
+          g11 = clamp101d(g11); g12 = clamp101d(g12); g22 = clamp101d(g22);
+        }
+        const double w0 = W[0][r], w1 = W[1][r], w2 = W[2][r];
+        W[0][r] = coeff * (g00 * w0 + g01 * w1 + g02 * w2);
+        W[1][r] = coeff * (g01 * w0 + g11 * w1 + g12 * w2);
+        W[2][r] = coeff * (g02 * w0 + g12 * w1 + g22 * w2);
+      }
+      // ---- Y += T^T . F : accumulator register r of a tile is the B operand of k-step r
+#pragma unroll
+      for (int e = 0; e < 3; ++e)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const double b = W[e][r];
+          const int row = e * NQP + 16 * qt + 4 * r + lg;
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) {
+            const int d = 16 * dt + lc;
+            const double a = d < 4 * KT ? T[row * KP + d] : 0.0;
+            Y[dt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, Y[dt], 0, 0, 0);
+          }
+        }
+    }
+    // ---- per-batch accumulation over unique dofs, then one atomic per unique dof
+    __syncthreads();   // every wave has finished reading Xu
+    for (int u = t; u < nu; u += NT) Xu[u] = 0.0;
+    __syncthreads();
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ks = 4 * dt + r;   // d = 16 dt + lg + 4 r = 4 ks + lg
+        if (ks < KT && 4 * ks + lg < nd) atomicAdd(&Xu[loc[ks < KT ? ks : 0]], Y[dt][r]);
+      }
+    __syncthreads();
+    for (int u = t; u < nu; u += NT) unsafeAtomicAdd(&y[uniq[u0 + u]], Xu[u]);
+  }
+}
+
+struct DenseOpData {
+  int nd = 0, nq = 0, QT = 0, KT = 0, DT = 0, nbatch = 0, numax = 0, nw = 4;
+  double* d_T = nullptr;
+  double* d_w = nullptr;
+  double* d_C = nullptr;
+  uint16_t* d_locT = nullptr;
+  int32_t* d_uoff = nullptr;
+  int32_t* d_uniq = nullptr;
+  size_t bytes = 0;
+};
+
+void dense_free(DenseOpData* d)
+{
+  if (!d) return;
+  (void)hipFree(d->d_T);
+  (void)hipFree(d->d_w);
+  (void)hipFree(d->d_C);
+  (void)hipFree(d->d_locT);
+  (void)hipFree(d->d_uoff);
+  (void)hipFree(d->d_uniq);
+  delete d;
+}
+
+template <typename Tp>
+static int up(Tp** p, const std::vector<Tp>& h, size_t* total)
+{
+  *p = nullptr;
+  if (h.empty()) return WF_OK;
+  WF_HIP_CHECK(hipMalloc((void**)p, h.size() * sizeof(Tp)));
+  WF_HIP_CHECK(hipMemcpy(*p, h.data(), h.size() * sizeof(Tp), hipMemcpyHostToDevice));
+  *total += h.size() * sizeof(Tp);
+  return WF_OK;
+}
+
+// Host setup: padded table, per-cell affine geometry C = |det J| K K^T, per-batch
+// unique-dof lists and local indices.
+int dense_setup(int nd, int nq, int ncells, int ndofs, const int32_t* dofmap, const double* dphi,
+                const double* weights, const double* xverts, const int32_t* geom_dofmap, DenseOpData** out)
+{
+  std::unique_ptr<DenseOpData, void (*)(DenseOpData*)> d(new DenseOpData, dense_free);
+  d->nd = nd;
+  d->nq = nq;
+  d->QT = (nq + 15) / 16;
+  d->KT = (nd + 3) / 4;
+  d->DT = (nd + 15) / 16;
+  d->nw = 4;
+  if (const char* e = std::getenv("WF_DENSE_WAVES")) d->nw = (std::atoi(e) == 8) ? 8 : 4;   // tuning hook
+  const int NCB = 16 * d->nw;
+  const int NQP = 16 * d->QT, KP = 4 * d->KT + 1;
+  std::vector<double> T((size_t)3 * NQP * KP, 0.0), w(NQP, 0.0);
+  for (int dir = 0; dir < 3; ++dir)
+    for (int q = 0; q < nq; ++q)
+      for (int k = 0; k < nd; ++k) T[((size_t)dir * NQP + q) * KP + k] = dphi[((size_t)dir * nq + q) * nd + k];
+  for (int q = 0; q < nq; ++q) w[q] = weights[q];
+  const int nbatch = (ncells + NCB - 1) / NCB;
+  d->nbatch = nbatch;
+  std::vector<double> C((size_t)nbatch * NCB * 6, 0.0);
+  for (int c = 0; c < ncells; ++c) {
+    const int32_t* v = geom_dofmap + (size_t)c * 4;
+    double J[9];
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) J[i * 3 + j] = xverts[(size_t)v[j + 1] * 3 + i] - xverts[(size_t)v[0] * 3 + i];
+    const double det = J[0] * (J[4] * J[8] - J[5] * J[7]) - J[1] * (J[3] * J[8] - J[5] * J[6])
+                       + J[2] * (J[3] * J[7] - J[4] * J[6]);
+    const double id = 1.0 / det;
+    double K[9];
+    K[0] = (J[4] * J[8] - J[5] * J[7]) * id;
+    K[1] = (J[2] * J[7] - J[1] * J[8]) * id;
+    K[2] = (J[1] * J[5] - J[2] * J[4]) * id;
+    K[3] = (J[5] * J[6] - J[3] * J[8]) * id;
+    K[4] = (J[0] * J[8] - J[2] * J[6]) * id;
+    K[5] = (J[2] * J[3] - J[0] * J[5]) * id;
+    K[6] = (J[3] * J[7] - J[4] * J[6]) * id;
+    K[7] = (J[1] * J[6] - J[0] * J[7]) * id;
+    K[8] = (J[0] * J[4] - J[1] * J[3]) * id;
+    const double ad = std::fabs(det);
+    auto kk = [&](int a, int b) {
+      double s = 0.0;
+      for (int m = 0; m < 3; ++m) s += (K[a * 3 + m] * ad) * K[b * 3 + m];
+      return s;
+    };
+    double* cc = &C[(size_t)c * 6];
+    cc[0] = kk(0, 0); cc[1] = kk(0, 1); cc[2] = kk(0, 2); cc[3] = kk(1, 1); cc[4] = kk(1, 2); cc[5] = kk(2, 2);
+  }
+  std::vector<uint16_t> locT((size_t)nbatch * 4 * d->KT * NCB, 0);
+  std::vector<int32_t> uoff(nbatch + 1, 0), uniq;
+  uniq.reserve((size_t)ncells * nd / 2);
+  std::vector<int32_t> tmp;
+  int numax = 0;
+  for (int b = 0; b < nbatch; ++b) {
+    const int c0 = b * NCB, nc = std::min(NCB, ncells - c0);
+    tmp.assign(dofmap + (size_t)c0 * nd, dofmap + (size_t)(c0 + nc) * nd);
+    std::sort(tmp.begin(), tmp.end());
+    tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+    const int nu = (int)tmp.size();
+    if (nu > 65535) {
+      set_error("dense_setup: more than 65535 unique dofs in a batch");
+      return WF_ERR_UNSUPPORTED;
+    }
+    numax = std::max(numax, nu);
+    for (int c = 0; c < nc; ++c)
+      for (int k = 0; k < nd; ++k) {
+        const int32_t g = dofmap[(size_t)(c0 + c) * nd + k];
+        const int u = (int)(std::lower_bound(tmp.begin(), tmp.end(), g) - tmp.begin());
+        locT[((size_t)b * 4 * d->KT + k) * NCB + c] = (uint16_t)u;
+      }
+    uniq.insert(uniq.end(), tmp.begin(), tmp.end());
+    uoff[b + 1] = (int32_t)uniq.size();
+  }
+  d->numax = std::max(numax, 1);
+  (void)ndofs;
+  int rc;
+  if ((rc = up(&d->d_T, T, &d->bytes)) != WF_OK) return rc;
+  if ((rc = up(&d->d_w, w, &d->bytes)) != WF_OK) return rc;
+  if ((rc = up(&d->d_C, C, &d->bytes)) != WF_OK) return rc;
+  if ((rc = up(&d->d_locT, locT, &d->bytes)) != WF_OK) return rc;
+  if ((rc = up(&d->d_uoff, uoff, &d->bytes)) != WF_OK) return rc;
+  if ((rc = up(&d->d_uniq, uniq, &d->bytes)) != WF_OK) return rc;
+  *out = d.release();
+  return WF_OK;
+}
+
+size_t dense_bytes(const DenseOpData* d) { return d ? d->bytes : 0; }
+
+template <int QT, int KT, int DT, int NW>
+static int launch_dense_t(const DenseOpData* d, double coeff, int do_clamp, const double* d_x, double* d_y,
+                          hipStream_t s)
+{
+  constexpr int NQP = 16 * QT, KP = 4 * KT + 1;
+  const size_t lds = ((size_t)3 * NQP * KP + NQP + d->numax) * sizeof(double);
+  if (lds > 160 * 1024) {
+    set_error("stiffness_dense: tables do not fit LDS");
+    return WF_ERR_UNSUPPORTED;
+  }
+  auto kern = k_stiffness_dense<QT, KT, DT, NW>;
+  if (lds > 64 * 1024)
+    WF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)lds));
+  const unsigned nb = (unsigned)std::min(d->nbatch, 256 * 2);   // persistent: the table is staged into LDS once per workgroup
+  hipLaunchKernelGGL(kern, dim3(nb), dim3(64 * NW), lds, s, d->nd, d->nq, d->nbatch, d->numax, d->d_T, d->d_w, d->d_C,
+                     d->d_locT, d->d_uoff, d->d_uniq, coeff, do_clamp, d_x, d_y);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error(std::string("stiffness_dense launch failed: ") + hipGetErrorString(e));
+    return WF_ERR_HIP;
+  }
+  return WF_OK;
+}
+
+#define WF_DENSE_CASE(Q, K, D)                                                                                   \
+  if (d->QT == Q && d->KT == K && d->DT == D)                                                                    \
+    return d->nw == 8 ? launch_dense_t<Q, K, D, 8>(d, coeff, do_clamp, d_x, d_y, s)                              \
+                      : launch_dense_t<Q, K, D, 4>(d, coeff, do_clamp, d_x, d_y, s);
+
+// Compiled shapes: Lagrange P1..P4 on the tetrahedron with the m = p Gauss-Jacobi
+// rule (nd, nq) = (4,1) (10,8) (20,27) (35,64), plus P4 with the m = 3 rule.
+int launch_stiffness_dense(const DenseOpData* d, double coeff, int do_clamp, const double* d_x, double* d_y,
+                           hipStream_t s)
+{
+  if (d->nbatch == 0) return WF_OK;
+  WF_DENSE_CASE(1, 1, 1)
+  WF_DENSE_CASE(1, 3, 1)
+  WF_DENSE_CASE(2, 5, 2)
+  WF_DENSE_CASE(4, 9, 3)
+  WF_DENSE_CASE(2, 9, 3)
+  set_error("stiffness_dense: (nd, nq) shape not compiled (supported: tetrahedron P1..P4)");
+  return WF_ERR_UNSUPPORTED;
+}
+
+}  // namespace wf
