@@ -527,3 +527,63 @@ def test_tet_dense_stiffness_vs_oracle(gpu, oracle, p, n, perturb):
     op(dev(x, gpu), y)
     assert relerr(y.cpu().numpy(), yref) <= 1e-11
     assert op.num_dofs() == K.nd and op.num_quads() == K.nq
+
+
+def test_full_size_cfg3_p6_mass(gpu):
+    """BASELINE configs[2] at full size (P6, 36^3 cells, 10 218 313 dofs): lumped
+    (spectral) mass in both forms and the dense Phi^T D Phi form (collocated rule)
+    agree; sum(M 1) = |Omega|; M is positive."""
+    import torch
+    import wave_fenics_amd as w
+    p, N = 6, 36
+    mesh = w.create_box(N, perturb=0.0)
+    V = w.create_functionspace(mesh, p)
+    n = V.ndofs
+    assert n == 10218313
+    ones = torch.ones(n, dtype=torch.float64, device=gpu)
+    m_box = torch.zeros_like(ones)
+    w.SpectralMassOperator(V, p, structured=True).apply(ones, m_box)
+    m_gen = torch.zeros_like(ones)
+    w.SpectralMassOperator(V, p, structured=False).apply(ones, m_gen)
+    assert abs(float(m_box.sum()) - 1.0) <= 1e-12 and float(m_box.min()) > 0
+    assert float((m_box - m_gen).abs().max()) <= 1e-13 * float(m_box.max())
+    pts, wts, _ = w.tabulate_gll(p)
+    W3 = np.einsum("k,j,i->kji", wts, wts, wts).reshape(-1)
+    detJ = np.tile(W3 / mesh.ncells, (mesh.ncells, 1))
+    m_dense = torch.zeros_like(ones)
+    w.MassOperator(V, p, np.eye(p + 1), detJ).apply(ones, m_dense)
+    assert float((m_dense - m_box).abs().max()) <= 1e-13 * float(m_box.max())
+    g = torch.Generator(device=gpu).manual_seed(2)
+    x = torch.rand(n, dtype=torch.float64, device=gpu, generator=g)
+    y = torch.zeros_like(x)
+    w.SpectralMassOperator(V, p, structured=True).apply(x, y)
+    assert float((y - m_box * x).abs().max()) <= 1e-15
+
+
+def test_full_size_cfg5_tets(gpu):
+    """BASELINE configs[4] at full size (P4 tetrahedra, Kuhn split of 54^3 cubes,
+    944 784 cells, 10 218 313 dofs): K 1 = 0, X^T K X = -c0^2 |Omega|, symmetry."""
+    import torch
+    from wave_fenics_amd import tet
+    p, N = 4, 54
+    V = tet.create_kuhn_box(N, p)
+    assert V.ncells == 944784 and V.ndofs == 10218313
+    op = tet.TetStiffnessOperator(V, p, {"c0": 1500.0})
+    n = V.ndofs
+    c02 = 1500.0 ** 2
+    y = torch.zeros(n, dtype=torch.float64, device=gpu)
+    op(torch.ones(n, dtype=torch.float64, device=gpu), y)
+    assert float(y.abs().max()) <= 1e-9 * c02
+    NX = V.lattice[0]
+    X = (torch.arange(NX, dtype=torch.float64, device=gpu) / (NX - 1)).repeat(V.lattice[1] * V.lattice[2])
+    y.zero_()
+    op(X, y)
+    assert abs(float(torch.dot(X, y)) / (-c02) - 1.0) <= 1e-10
+    g = torch.Generator(device=gpu).manual_seed(3)
+    u = torch.rand(n, dtype=torch.float64, device=gpu, generator=g) - 0.5
+    v = torch.rand(n, dtype=torch.float64, device=gpu, generator=g) - 0.5
+    Ku, Kv = torch.zeros_like(u), torch.zeros_like(u)
+    op(u, Ku)
+    op(v, Kv)
+    a, b = float(torch.dot(v, Ku)), float(torch.dot(u, Kv))
+    assert abs(a - b) <= 1e-10 * abs(a)

@@ -30,11 +30,13 @@ namespace wf {
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
+// xt::isclose clamp to -1/0/1 (precomputation.hpp:105-107); the common case
+// (no clamp zone hit) costs two compares.
 __device__ __forceinline__ double clamp101d(double v)
 {
-  if (fabs(v + 1.0) <= 1e-8 + 1e-5) v = -1.0;
-  if (fabs(v) <= 1e-8) v = 0.0;
-  if (fabs(v - 1.0) <= 1e-8 + 1e-5) v = 1.0;
+  const double a = fabs(v);
+  if (a <= 1e-8) return 0.0;
+  if (fabs(a - 1.0) <= 1e-8 + 1e-5) return v < 0.0 ? -1.0 : 1.0;
   return v;
 }
 
