@@ -90,3 +90,14 @@ def test_cxx_wrappers_compile_and_link(wlib, tmp_path):
     assert out.returncode == 0, out.stderr
     a, b = out.stdout.split()
     assert abs(float(a) - 0.1726731646460114) < 1e-15 and abs(float(b) - 13.513004977448478) < 1e-12
+
+
+def test_cxx_host_drivers_build(wlib, tmp_path):
+    """examples/planar3d.cpp and operator_demo.cpp (the C++ host side over the C
+    ABI) compile and link; their usage errors work without a GPU."""
+    import subprocess
+    out = str(tmp_path / "bin")
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "examples"), f"OUT={out}", "CXXFLAGS=-O1 -std=c++17 -Wall -Werror"])
+    for exe in ("planar3d", "operator_demo"):
+        r = subprocess.run([os.path.join(out, exe), "--bogus"], capture_output=True, text=True, timeout=60)
+        assert r.returncode == 2 and "usage" in r.stderr

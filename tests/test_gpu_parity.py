@@ -587,3 +587,42 @@ def test_full_size_cfg5_tets(gpu):
     op(v, Kv)
     a, b = float(torch.dot(v, Ku)), float(torch.dot(u, Kv))
     assert abs(a - b) <= 1e-10 * abs(a)
+
+
+def test_cxx_host_driver_cfg1(gpu, oracle, tmp_path):
+    """The C++ host side (include/wavehip_linear_gll.hpp: class LinearGLLOpt with
+    the reference's members and call order, examples/planar3d.cpp = the reference's
+    demo/cpu_planar3d/main.cpp) on BASELINE cfg1: P2, 18^3 cells, 100 RK4 steps,
+    against the oracle to 1e-9; plus the operator demo's printed norms."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "bin")
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "examples"), f"OUT={out}"])
+    p, N = 2, 18
+    hi = (0.01, 0.01, 0.01)
+    om = oracle.create_box(N, p, hi=hi)
+    ref = oracle.LinearGLLOpt(om, p, 1500.0, 0.5e6, 6e4)
+    dt, spp = oracle.cfl_time_step(om, p, 1500.0, 0.5e6, CFL=0.25)
+    ref.init()
+    ref.rk4(0.0, 100 * dt - 1e-13, dt)
+    dump = str(tmp_path / "uv.bin")
+    r = subprocess.run([os.path.join(out, "planar3d"), "--size", str(N), "--degree", str(p), "--cfl", "0.25",
+                        "--steps", "100", "--length", "0.01", "--dump", dump], capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert f"Number of step per period: {spp}" in r.stdout
+    assert "Steps taken: 100" in r.stdout and f"Degrees of freedom: {om.ndofs}" in r.stdout
+    uv = np.fromfile(dump, dtype=np.float64)
+    assert uv.size == 2 * om.ndofs
+    assert relerr(uv[: om.ndofs], ref.u_n) <= 1e-9
+    assert relerr(uv[om.ndofs:], ref.v_n) <= 1e-9
+    # operator demo: lumped mass with x = 1 (the reference's --check input)
+    om4 = oracle.create_box(6, 4)
+    m = np.zeros(om4.ndofs)
+    oracle.MassOperatorCPU(om4, 4)(np.ones(om4.ndofs), m)
+    r = subprocess.run([os.path.join(out, "operator_demo"), "--size", "6", "--degree", "4", "--op", "mass", "--reps", "2"],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    vals = {l.split(":")[0].strip(): l.split(":")[1].strip() for l in r.stdout.splitlines() if ":" in l}
+    assert abs(float(vals["Y norm"]) - np.linalg.norm(m)) <= 1e-5 * np.linalg.norm(m)     # printed with 6 digits
+    assert int(vals["Number of cells"]) == 216 and int(vals["Number of dofs"]) == 125
