@@ -154,18 +154,22 @@ def main():
     if updater is not None:
         # cells that read no ghost value run while the halo of x is in flight
         split = K.set_ghost_faces(*[bool(v) for v in part.owned_lo])
-    from wave_fenics_amd._lib import WF_PART_INTERFACE, WF_PART_INTERIOR
+    from wave_fenics_amd._lib import WF_PART_INTERFACE, WF_PART_INTERIOR, WF_PART_INTERIOR_A, WF_PART_INTERIOR_B
 
     def step(ev=None):
         if split:
+            # forward halo under interior half A, reverse (add) halo under half B
             updater.update_fwd_begin(x)
             if ev is not None:
                 ev[0].record()
-            K.apply_part(x, y, WF_PART_INTERIOR)
+            K.apply_part(x, y, WF_PART_INTERIOR_A)
             if ev is not None:
                 ev[1].record()
             updater.update_fwd_end(x)
             K.apply_part(x, y, WF_PART_INTERFACE)
+            updater.update_rev_begin(y)
+            K.apply_part(x, y, WF_PART_INTERIOR_B)
+            updater.update_rev_end(y)
         else:
             if updater is not None:
                 updater.scatter_fwd(x)
@@ -174,8 +178,8 @@ def main():
             K(x, y)
             if ev is not None:
                 ev[1].record()
-        if updater is not None:
-            updater.scatter_rev(y)
+            if updater is not None:
+                updater.scatter_rev(y)
         la.pointwise_div(y, m, kv)
 
     def sync():
@@ -205,7 +209,7 @@ def main():
         alg = K.alg_bytes()
         if split:
             # the timed launch covered the interior work items only
-            alg *= K.part_fraction(WF_PART_INTERIOR)
+            alg *= 0.5 * K.part_fraction(WF_PART_INTERIOR)
         achieved = alg / (kern_ms * 1e-3) / 1e9
         traffic = None
         tp = os.path.join(ROOT, "profiles", "traffic.json")

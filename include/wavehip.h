@@ -161,7 +161,13 @@ int wf_op_apply(wf_op* op, const double* d_x, double* d_y, void* stream);
  * (VectorUpdater::update_fwd_begin/_end, demo/gpu_scatter_mpi/VectorUpdater.hpp:106-143)
  * with the cells that read no ghost value.  ghost_*0 != 0 marks the lower lattice
  * plane of that axis as a ghost plane.  apply(INTERIOR) + apply(INTERFACE) == apply. */
-typedef enum { WF_PART_ALL = 0, WF_PART_INTERIOR = 1, WF_PART_INTERFACE = 2 } wf_part;
+typedef enum {
+  WF_PART_ALL = 0,
+  WF_PART_INTERIOR = 1,    /* every cell that reads no ghost value                       */
+  WF_PART_INTERFACE = 2,
+  WF_PART_INTERIOR_A = 3,  /* INTERIOR split in two halves: A hides the forward halo,    */
+  WF_PART_INTERIOR_B = 4   /* B the reverse (add) halo; A + B == INTERIOR                */
+} wf_part;
 int wf_op_set_ghost_faces(wf_op* op, int ghost_x0, int ghost_y0, int ghost_z0);
 int wf_op_apply_part(wf_op* op, const double* d_x, double* d_y, int part, void* stream);
 

@@ -182,6 +182,12 @@ def test_interior_interface_split(gpu, oracle, ghost, monkeypatch):
     assert bool(torch.isfinite(ya).all()), "interior part read a ghost plane"
     op.apply_part(x, ya, WF_PART_INTERFACE)
     assert relerr(ya.cpu().numpy(), yall.cpu().numpy()) <= 1e-13
+    # the two interior halves (forward halo under A, reverse halo under B) add up to INTERIOR
+    from wave_fenics_amd._lib import WF_PART_INTERIOR_A, WF_PART_INTERIOR_B
+    yb = torch.zeros_like(x)
+    for part in (WF_PART_INTERIOR_A, WF_PART_INTERFACE, WF_PART_INTERIOR_B):
+        op.apply_part(x, yb, part)
+    assert relerr(yb.cpu().numpy(), yall.cpu().numpy()) <= 1e-13
     if ghost == (0, 0, 0):
         assert op.info.items_interface == 0
     opg = w.StiffnessOperator(V, p, structured=False)

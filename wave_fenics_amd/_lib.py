@@ -45,7 +45,7 @@ class OpInfo(ctypes.Structure):
 
 WF_OP_STIFFNESS, WF_OP_MASS_LUMPED, WF_OP_MASS_DENSE = 0, 1, 2
 WF_FLAG_NONE, WF_FLAG_NO_FABS, WF_FLAG_NO_CLAMP = 0, 1, 2
-WF_PART_ALL, WF_PART_INTERIOR, WF_PART_INTERFACE = 0, 1, 2
+WF_PART_ALL, WF_PART_INTERIOR, WF_PART_INTERFACE, WF_PART_INTERIOR_A, WF_PART_INTERIOR_B = 0, 1, 2, 3, 4
 
 # every symbol include/wavehip.h declares: name -> (restype, argtypes)
 _dp, _ip, _vp = POINTER(c_double), POINTER(c_int32), c_void_p

@@ -22,8 +22,9 @@ struct wf_op {
   double* d_D = nullptr;
   double* d_phi1 = nullptr;
   double* d_mdiag = nullptr;
-  int32_t* d_items[2] = {nullptr, nullptr};   // [0] interior, [1] interface work items (marching kernel)
-  int nitems[2] = {0, 0};
+  // work-item lists of the marching kernel: [0] interior, [1] interface, [2]/[3] the two halves of the interior
+  int32_t* d_items[4] = {nullptr, nullptr, nullptr, nullptr};
+  int nitems[4] = {0, 0, 0, 0};
   int have_parts = 0;
   DenseOpData* dense = nullptr;   // dense simplex operator (stiffness_dense.hip)
   int dense_clamp = 1;
@@ -70,8 +71,7 @@ void free_op(wf_op* op)
   (void)hipFree(op->d_D);
   (void)hipFree(op->d_phi1);
   (void)hipFree(op->d_mdiag);
-  (void)hipFree(op->d_items[0]);
-  (void)hipFree(op->d_items[1]);
+  for (int k = 0; k < 4; ++k) (void)hipFree(op->d_items[k]);
   dense_free(op->dense);
   delete op;
 }
@@ -501,7 +501,7 @@ int wf_op_set_ghost_faces(wf_op* op, int ghost_x0, int ghost_y0, int ghost_z0)
   }
   const int nbx = (op->nx + op->bx - 1) / op->bx, nby = (op->ny + op->by - 1) / op->by;
   const int ncols = nbx * nby, nseg = (op->nz + op->lz - 1) / op->lz;
-  std::vector<int32_t> items[2];
+  std::vector<int32_t> items[4];
   for (int seg = 0; seg < nseg; ++seg)
     for (int col = 0; col < ncols; ++col) {
       const int Bx = col % nbx, By = col / nbx;
@@ -509,7 +509,10 @@ int wf_op_set_ghost_faces(wf_op* op, int ghost_x0, int ghost_y0, int ghost_z0)
       const bool iface = (ghost_x0 && Bx == 0) || (ghost_y0 && By == 0) || (ghost_z0 && seg == 0);
       items[iface ? 1 : 0].push_back(col + ncols * seg);
     }
-  for (int k = 0; k < 2; ++k) {
+  // the interior halves let a caller hide BOTH halo directions: forward update under
+  // half A, reverse update under half B (alternate items so both halves span the mesh)
+  for (size_t q = 0; q < items[0].size(); ++q) items[2 + (q & 1)].push_back(items[0][q]);
+  for (int k = 0; k < 4; ++k) {
     (void)hipFree(op->d_items[k]);
     op->d_items[k] = nullptr;
     op->nitems[k] = (int)items[k].size();
@@ -526,12 +529,12 @@ int wf_op_apply_part(wf_op* op, const double* d_x, double* d_y, int part, void* 
 {
   WF_REQUIRE(op && d_x && d_y, "wf_op_apply_part: null argument");
   if (part == WF_PART_ALL) return wf_op_apply(op, d_x, d_y, stream);
-  WF_REQUIRE(part == WF_PART_INTERIOR || part == WF_PART_INTERFACE, "wf_op_apply_part: unknown part");
+  WF_REQUIRE(part >= WF_PART_INTERIOR && part <= WF_PART_INTERIOR_B, "wf_op_apply_part: unknown part");
   if (!op->have_parts) {
     set_error("wf_op_apply_part: call wf_op_set_ghost_faces first");
     return WF_ERR_INVALID;
   }
-  const int k = part == WF_PART_INTERIOR ? 0 : 1;
+  const int k = part - 1;   // WF_PART_INTERIOR, _INTERFACE, _INTERIOR_A, _INTERIOR_B
   if (op->nitems[k] == 0) return WF_OK;
   return launch_stiffness_march(op->P, op->march_variant, op->nx, op->ny, op->nz, op->lz, op->d_G6blk, op->d_D, op->dm,
                                 op->coeff, d_x, d_y, op->d_items[k], op->nitems[k], (hipStream_t)stream);

@@ -145,15 +145,23 @@ class LinearGLLOpt:
             # same operations as below, reordered so that the cells that read no ghost
             # value run while the halo of u is in flight (update_fwd_begin/_end,
             # VectorUpdater.hpp:106-143)
-            from ._lib import WF_PART_INTERFACE, WF_PART_INTERIOR
+            from ._lib import WF_PART_INTERFACE, WF_PART_INTERIOR_A, WF_PART_INTERIOR_B
             la.fill(self.b, 0.0)
             self.updater.update_fwd_begin(u)
-            self.stiff_op.apply_part(u, self.b, WF_PART_INTERIOR)
+            self.stiff_op.apply_part(u, self.b, WF_PART_INTERIOR_A)
             self.updater.update_fwd_end(u)
             la.copy(u, self.u_n)
             self.updater.scatter_fwd(v)
             la.copy(v, self.v_n)
             self.stiff_op.apply_part(self.u_n, self.b, WF_PART_INTERFACE)
+            la.boundary_apply(self.idx1, self.mG1, self.c0_ ** 2 * self.g_,
+                              self.idx2, self.mG2, -self.c0_, self.v_n, self.b)
+            # reverse (add) halo of b under the second half of the interior cells
+            self.updater.update_rev_begin(self.b)
+            self.stiff_op.apply_part(self.u_n, self.b, WF_PART_INTERIOR_B)
+            self.updater.update_rev_end(self.b)
+            la.pointwise_div(self.b, self.m, result)
+            return
         else:
             if self.updater is not None:
                 self.updater.scatter_fwd(u)
@@ -215,7 +223,7 @@ def _rk4_fused(self, startTime: float, finalTime: float, timeStep: float, max_st
     the stage-0 copies removed by pointer rotation: per stage
     K (116 B/dof at P4) + 96 B/dof instead of K + 208 B/dof.  Same arithmetic
     expressions as the unfused loop."""
-    from ._lib import WF_PART_INTERFACE, WF_PART_INTERIOR
+    from ._lib import WF_PART_INTERFACE, WF_PART_INTERIOR_A, WF_PART_INTERIOR_B
     t, tf, dt = startTime, finalTime, timeStep
     step = 0
     new = lambda: torch.zeros_like(self.u_n)
@@ -236,16 +244,21 @@ def _rk4_fused(self, startTime: float, finalTime: float, timeStep: float, max_st
             window = 1.0
         g = window * self.p0_ * self.w0_ / self.c0_ * math.cos(self.w0_ * tn)
         if self._split:
+            # forward halo of u under interior half A, reverse halo of b under half B
             upd.update_fwd_begin(x_u)
-            self.stiff_op.apply_part(x_u, b, WF_PART_INTERIOR)
+            self.stiff_op.apply_part(x_u, b, WF_PART_INTERIOR_A)
             upd.update_fwd_end(x_u)
             upd.scatter_fwd(x_v)
             self.stiff_op.apply_part(x_u, b, WF_PART_INTERFACE)
-        else:
-            if upd is not None:
-                upd.scatter_fwd(x_u)
-                upd.scatter_fwd(x_v)
-            self.stiff_op(x_u, b)
+            la.boundary_apply(self.idx1, self.mG1, self.c0_ ** 2 * g, self.idx2, self.mG2, -self.c0_, x_v, b)
+            upd.update_rev_begin(b)
+            self.stiff_op.apply_part(x_u, b, WF_PART_INTERIOR_B)
+            upd.update_rev_end(b)
+            return
+        if upd is not None:
+            upd.scatter_fwd(x_u)
+            upd.scatter_fwd(x_v)
+        self.stiff_op(x_u, b)
         la.boundary_apply(self.idx1, self.mG1, self.c0_ ** 2 * g, self.idx2, self.mG2, -self.c0_, x_v, b)
         if upd is not None:
             upd.scatter_rev(b)
