@@ -22,6 +22,11 @@ struct wf_op {
   double* d_D = nullptr;
   double* d_phi1 = nullptr;
   double* d_mdiag = nullptr;
+  // batch-unique gather/scatter lists of the generic stiffness kernel
+  int32_t* d_uoff = nullptr;
+  int32_t* d_uniq = nullptr;
+  uint16_t* d_loc = nullptr;
+  int generic_unique = 0;
   // work-item lists of the marching kernel: [0] interior, [1] interface, [2]/[3] the two halves of the interior
   int32_t* d_items[4] = {nullptr, nullptr, nullptr, nullptr};
   int nitems[4] = {0, 0, 0, 0};
@@ -71,6 +76,9 @@ void free_op(wf_op* op)
   (void)hipFree(op->d_D);
   (void)hipFree(op->d_phi1);
   (void)hipFree(op->d_mdiag);
+  (void)hipFree(op->d_uoff);
+  (void)hipFree(op->d_uniq);
+  (void)hipFree(op->d_loc);
   for (int k = 0; k < 4; ++k) (void)hipFree(op->d_items[k]);
   dense_free(op->dense);
   delete op;
@@ -295,6 +303,29 @@ int wf_op_create(const wf_op_desc* desc, wf_op** out)
   if (desc->kind == WF_OP_STIFFNESS) {
     const int CB = cells_per_batch(P);
     const size_t nbatch = (ncells + CB - 1) / CB;
+    // batch-unique dof lists (WF_GENERIC=flat keeps the element-wise scatter for comparison)
+    const char* gk = std::getenv("WF_GENERIC");
+    if (!(gk && std::strcmp(gk, "flat") == 0) && ncells) {
+      std::vector<int32_t> tdm(ncells * nd);
+      WF_HIP_CHECK(hipMemcpy(tdm.data(), op->d_dofmap, tdm.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+      std::vector<int32_t> uoff(nbatch + 1, 0), uniq, tmp;
+      std::vector<uint16_t> loc(ncells * nd);
+      uniq.reserve(ncells * nd / 2);
+      for (size_t b = 0; b < nbatch; ++b) {
+        const size_t c0 = b * CB, nc = std::min<size_t>(CB, ncells - c0);
+        tmp.assign(tdm.begin() + c0 * nd, tdm.begin() + (c0 + nc) * nd);
+        std::sort(tmp.begin(), tmp.end());
+        tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+        for (size_t e = c0 * nd; e < (c0 + nc) * nd; ++e)
+          loc[e] = (uint16_t)(std::lower_bound(tmp.begin(), tmp.end(), tdm[e]) - tmp.begin());
+        uniq.insert(uniq.end(), tmp.begin(), tmp.end());
+        uoff[b + 1] = (int32_t)uniq.size();
+      }
+      if ((rc = dev_upload(&op->d_uoff, uoff.data(), uoff.size(), &op->device_bytes)) != WF_OK) return rc;
+      if ((rc = dev_upload(&op->d_uniq, uniq.data(), uniq.size(), &op->device_bytes)) != WF_OK) return rc;
+      if ((rc = dev_upload(&op->d_loc, loc.data(), loc.size(), &op->device_bytes)) != WF_OK) return rc;
+      op->generic_unique = 1;
+    }
     const size_t g6 = nbatch * CB * nd * 6;
     if ((rc = dev_alloc(&op->d_G6blk, g6, &op->device_bytes)) != WF_OK) return rc;
     if (g6) WF_HIP_CHECK(hipMemset(op->d_G6blk, 0, g6 * sizeof(double)));
@@ -481,6 +512,9 @@ int wf_op_apply(wf_op* op, const double* d_x, double* d_y, void* stream)
   }
   switch (op->kind) {
     case WF_OP_STIFFNESS:
+      if (op->generic_unique)
+        return launch_stiffness_generic_u(op->P, op->ncells, op->d_uoff, op->d_uniq, op->d_loc, op->d_G6blk, op->d_D,
+                                          op->dm, op->coeff, d_x, d_y, s);
       return launch_stiffness_generic(op->P, op->ncells, op->d_dofmap, op->d_G6blk, op->d_D, op->dm, op->coeff, d_x,
                                       d_y, s);
     case WF_OP_MASS_LUMPED:

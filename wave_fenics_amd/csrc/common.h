@@ -57,6 +57,9 @@ int launch_pack_G6(int P, int ncells, const double* d_G9, double* d_G6blk, hipSt
 int launch_stiffness_generic(int P, int ncells, const int32_t* d_dofmap, const double* d_G6blk,
                              const double* d_D, const DMat& dm, double coeff, const double* d_x,
                              double* d_y, hipStream_t s);
+int launch_stiffness_generic_u(int P, int ncells, const int32_t* d_uoff, const int32_t* d_uniq, const uint16_t* d_loc,
+                               const double* d_G6blk, const double* d_D, const DMat& dm, double coeff,
+                               const double* d_x, double* d_y, hipStream_t s);
 int launch_stiffness_box(int P, int nx, int ny, int nz, int bx, int by, int bz, const double* d_G6blk,
                          const double* d_D, const DMat& dm, double coeff, const double* d_x, double* d_y,
                          hipStream_t s);

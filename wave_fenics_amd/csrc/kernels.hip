@@ -293,6 +293,93 @@ __global__ __launch_bounds__(256) void k_stiffness_generic(int ncells, const int
 // structured box stiffness: implicit dofmap, block dof tile in LDS, atomics only
 // on dofs shared with a neighbouring block
 // --------------------------------------------------------------------------
+// --------------------------------------------------------------------------
+// generic stiffness, batch-unique form (default for arbitrary dofmaps): the host
+// lists the unique dofs of every batch of CB cells once (uniq, sorted) and the
+// position of every element-local dof in that list (loc, uint16).  x is read once
+// per unique dof, the cells of the batch are summed per unique dof in LDS
+// (ds_add_f64) and y receives ONE atomic per unique dof, in ascending address
+// order -- fewer and better-shaped atomic requests than the element-wise scatter
+// (P4, lexicographic numbering: 1025 instead of 1250 per batch, runs of 41
+// contiguous doubles instead of 5).
+// --------------------------------------------------------------------------
+template <int P>
+__global__ __launch_bounds__(256) void k_stiffness_generic_u(int ncells, const int32_t* __restrict__ uoff,
+                                                             const int32_t* __restrict__ uniq,
+                                                             const uint16_t* __restrict__ loc,
+                                                             const double2* __restrict__ G6blk,
+                                                             const double* __restrict__ dD, DMat dm,
+                                                             double coeff, const double* __restrict__ x,
+                                                             double* __restrict__ y, int ablate)
+{
+  constexpr int n = P + 1, n2 = n * n, nd = n * n2;
+  constexpr int CB = 256 / n2, NT = CB * n2;
+  constexpr int NFLAT = (CB * nd + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* U = smem;                 // [CB][nd]
+  double* Fr = U + CB * nd;         // [CB][nd]; also the unique-dof tile before phase 1 and after phase 2
+  double* Fs = Fr + CB * nd;        // [CB][nd]
+  double* sD = Fs + CB * nd;        // [n][n]
+
+  const int t = threadIdx.x;
+  const size_t batch = blockIdx.x;
+  const int cell0 = (int)batch * CB;
+  const bool active = t < NT;
+  const int cl = t / n2, ji = t % n2, j = ji / n, i = ji % n;
+
+  double2 g[n][3];
+  if (active) {
+    const double2* gp = G6blk + (batch * n * 3) * (size_t)NT + t;
+    if (ablate & 2) gp = G6blk + t;
+#pragma unroll
+    for (int k = 0; k < n; ++k)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) g[k][p] = gp[(size_t)(k * 3 + p) * NT];
+  }
+  if (t < n * n) sD[t] = dD[t];
+
+  const int u0 = uoff[batch], nu = uoff[batch + 1] - u0;
+  for (int u = t; u < nu; u += 256) Fr[u] = (ablate & 4) ? 1.0 + u : x[uniq[u0 + u]];
+  uint16_t lc[NFLAT];
+  const int nvalid = min(CB, ncells - cell0) * nd;
+#pragma unroll
+  for (int m = 0; m < NFLAT; ++m) {
+    const int pos = t + 256 * m;
+    lc[m] = pos < nvalid ? loc[(size_t)cell0 * nd + pos] : (uint16_t)0xFFFF;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int m = 0; m < NFLAT; ++m) {
+    const int pos = t + 256 * m;
+    if (pos < CB * nd) U[pos] = lc[m] != 0xFFFF ? Fr[lc[m]] : 0.0;
+  }
+  __syncthreads();
+
+  double out[n];
+  stiffness_column<P>(U + cl * nd, n2, n, Fr + cl * nd, Fs + cl * nd, sD, dm, g, coeff, i, j, active, out, ablate);
+
+  if (active) {
+#pragma unroll
+    for (int k = 0; k < n; ++k) U[cl * nd + k * n2 + ji] = out[k];
+  }
+  __syncthreads();   // phase 2 has read Fr/Fs, U holds the element results
+  for (int u = t; u < nu; u += 256) Fr[u] = 0.0;
+  __syncthreads();
+#pragma unroll
+  for (int m = 0; m < NFLAT; ++m) {
+    const int pos = t + 256 * m;
+    if (lc[m] != 0xFFFF) atomicAdd(&Fr[lc[m]], U[pos]);
+  }
+  __syncthreads();
+  for (int u = t; u < nu; u += 256) {
+    if (ablate & 1) {
+      if (Fr[u] == 1.2345e300) y[uniq[u0 + u]] = Fr[u];
+    } else {
+      unsafeAtomicAdd(&y[uniq[u0 + u]], Fr[u]);
+    }
+  }
+}
+
 template <int P>
 __global__ __launch_bounds__(256) void k_stiffness_box(int nx, int ny, int nz, int bx, int by, int bz,
                                                        const double2* __restrict__ G6blk,
@@ -553,6 +640,38 @@ static int launch_stiffness_generic_t(int ncells, const int32_t* d_dofmap, const
                      reinterpret_cast<const double2*>(d_G6blk), d_D, dm, coeff, d_x, d_y, ablate_flags());
   WF_LAUNCH_CHECK();
   return WF_OK;
+}
+
+template <int P>
+static int launch_stiffness_generic_u_t(int ncells, const int32_t* d_uoff, const int32_t* d_uniq,
+                                        const uint16_t* d_loc, const double* d_G6blk, const double* d_D,
+                                        const DMat& dm, double coeff, const double* d_x, double* d_y, hipStream_t s)
+{
+  constexpr int n = P + 1, nd = n * n * n, CB = 256 / (n * n);
+  const unsigned nb = (unsigned)((ncells + CB - 1) / CB);
+  const size_t lds = (size_t)(3 * CB * nd + n * n) * sizeof(double);
+  hipLaunchKernelGGL(k_stiffness_generic_u<P>, dim3(nb), dim3(256), lds, s, ncells, d_uoff, d_uniq, d_loc,
+                     reinterpret_cast<const double2*>(d_G6blk), d_D, dm, coeff, d_x, d_y, ablate_flags());
+  WF_LAUNCH_CHECK();
+  return WF_OK;
+}
+
+int launch_stiffness_generic_u(int P, int ncells, const int32_t* d_uoff, const int32_t* d_uniq, const uint16_t* d_loc,
+                               const double* d_G6blk, const double* d_D, const DMat& dm, double coeff,
+                               const double* d_x, double* d_y, hipStream_t s)
+{
+  if (ncells == 0) return WF_OK;
+  switch (P) {
+    case 1: return launch_stiffness_generic_u_t<1>(ncells, d_uoff, d_uniq, d_loc, d_G6blk, d_D, dm, coeff, d_x, d_y, s);
+    case 2: return launch_stiffness_generic_u_t<2>(ncells, d_uoff, d_uniq, d_loc, d_G6blk, d_D, dm, coeff, d_x, d_y, s);
+    case 3: return launch_stiffness_generic_u_t<3>(ncells, d_uoff, d_uniq, d_loc, d_G6blk, d_D, dm, coeff, d_x, d_y, s);
+    case 4: return launch_stiffness_generic_u_t<4>(ncells, d_uoff, d_uniq, d_loc, d_G6blk, d_D, dm, coeff, d_x, d_y, s);
+    case 5: return launch_stiffness_generic_u_t<5>(ncells, d_uoff, d_uniq, d_loc, d_G6blk, d_D, dm, coeff, d_x, d_y, s);
+    case 6: return launch_stiffness_generic_u_t<6>(ncells, d_uoff, d_uniq, d_loc, d_G6blk, d_D, dm, coeff, d_x, d_y, s);
+    case 7: return launch_stiffness_generic_u_t<7>(ncells, d_uoff, d_uniq, d_loc, d_G6blk, d_D, dm, coeff, d_x, d_y, s);
+  }
+  set_error("stiffness: degree must be 1..7");
+  return WF_ERR_UNSUPPORTED;
 }
 
 int launch_stiffness_generic(int P, int ncells, const int32_t* d_dofmap, const double* d_G6blk,
