@@ -457,8 +457,21 @@ int wf_op_create_box(int kind, int degree, int nx, int ny, int nz, const double*
       }
       op->bz = 1;
       const int ncols = ((nx + op->bx - 1) / op->bx) * ((ny + op->by - 1) / op->by);
-      int nseg = std::max(1, std::min(nz, (1536 + ncols / 2) / ncols));
-      op->lz = (nz + nseg - 1) / nseg;
+      // z segmentation: work items = columns x segments run in rounds of the 512
+      // resident workgroups (2 per CU); each item pays ~1.5 layers of pipeline fill.
+      // Pick the segment length that minimises rounds * (lz + 1.5).
+      double best = 1e300;
+      op->lz = nz;
+      for (int nseg = 1; nseg <= nz; ++nseg) {
+        const int lz = (nz + nseg - 1) / nseg;
+        if (lz < 3 && nseg > 1) break;
+        const long items = (long)ncols * ((nz + lz - 1) / lz);
+        const double cost = (double)((items + 511) / 512) * (lz + 1.5);
+        if (cost < best - 1e-9) {
+          best = cost;
+          op->lz = lz;
+        }
+      }
       if (const char* l = std::getenv("WF_MARCH_LZ")) op->lz = std::max(1, std::atoi(l));
     }
   }
