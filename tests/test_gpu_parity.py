@@ -632,3 +632,41 @@ def test_cxx_host_driver_cfg1(gpu, oracle, tmp_path):
     vals = {l.split(":")[0].strip(): l.split(":")[1].strip() for l in r.stdout.splitlines() if ":" in l}
     assert abs(float(vals["Y norm"]) - np.linalg.norm(m)) <= 1e-5 * np.linalg.norm(m)     # printed with 6 digits
     assert int(vals["Number of cells"]) == 216 and int(vals["Number of dofs"]) == 125
+
+
+def test_generic_ops_random_cell_order(gpu, oracle):
+    """Arbitrary cell order (the operators sort cells internally by their smallest
+    dof) with every way of handing over the per-cell data: G / detJ arrays in the
+    caller's cell order, or the mesh."""
+    import wave_fenics_amd as w
+    p, n = 3, (4, 3, 3)
+    om, mesh, V = make(oracle, n, p)
+    rng = np.random.default_rng(21)
+    cp = rng.permutation(om.ncells)
+    gperm = rng.permutation(om.ndofs).astype(np.int32)
+    dm = gperm[om.dofmap][cp]
+    m2 = w.BoxMesh(mesh.n, mesh.x, np.ascontiguousarray(mesh.geom_dofmap[cp]))
+    V2 = w.FunctionSpace(m2, p, np.ascontiguousarray(dm), w.IndexMap(om.ndofs), V.lattice, structured=False)
+    K = oracle.StiffnessOperator(om, p)
+    M = oracle.MassOperatorCPU(om, p)
+    x = rng.uniform(-1, 1, om.ndofs)
+    xp = np.empty_like(x)
+    xp[gperm] = x
+    yK, yM = np.zeros(om.ndofs), np.zeros(om.ndofs)
+    K(x, yK)
+    M(x, yM)
+    for kw in (dict(G=K.G[cp]), dict()):
+        y = dev(np.zeros(om.ndofs), gpu)
+        w.StiffnessOperator(V2, p, {"c0": 1500.0}, structured=False, **kw)(dev(xp, gpu), y)
+        assert relerr(y.cpu().numpy()[gperm], yK) <= 1e-11
+    for kw in (dict(detJ=M.detJ[cp]), dict()):
+        y = dev(np.zeros(om.ndofs), gpu)
+        w.MassOperatorLumped(V2, p, structured=False, **kw)(dev(xp, gpu), y)
+        assert relerr(y.cpu().numpy()[gperm], yM) <= 1e-13
+    pts, wts, phi1, phi, X, W = oracle.tabulate_mass_tables(p, "equispaced", "gauss_jacobi", 2 * p)
+    detq = oracle.compute_detJ_generic(om, X, W)
+    yD = np.zeros(om.ndofs)
+    oracle.dense_mass_apply(om, phi, detq, x, yD)
+    y = dev(np.zeros(om.ndofs), gpu)
+    w.MassOperator(V2, p, phi1, detq[cp]).apply(dev(xp, gpu), y)
+    assert relerr(y.cpu().numpy()[gperm], yD) <= 1e-12

@@ -1,0 +1,54 @@
+"""Diagnostic: the generic (arbitrary dofmap) stiffness kernel under hostile
+orderings of the same cfg2 mesh: lexicographic, random cell order, random dof
+numbering, both.  Not part of the product."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import wave_fenics_amd as w  # noqa: E402
+
+
+def time_op(op, x, y, reps=15):
+    for _ in range(3):
+        op(x, y)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for a, b in ev:
+        a.record()
+        op(x, y)
+        b.record()
+    torch.cuda.synchronize()
+    return float(np.median([a.elapsed_time(b) for a, b in ev]))
+
+
+def main():
+    p = int(os.environ.get("P", "4"))
+    n = int(os.environ.get("N", "54"))
+    dev = torch.device("cuda", 0)
+    mesh = w.create_box(n)
+    V = w.create_functionspace(mesh, p)
+    rng = np.random.default_rng(0)
+    x = torch.rand(V.ndofs, dtype=torch.float64, device=dev)
+    y = torch.zeros_like(x)
+    cperm = rng.permutation(mesh.ncells)
+    dperm = rng.permutation(V.ndofs).astype(np.int32)
+    # "DOLFINx-like": cells in blocks of 4^3 visited in random block order, dofs numbered by first touch
+    for name, cp, dp in (("lexicographic", None, None), ("random cell order", cperm, None),
+                         ("random dof numbering", None, dperm), ("both random", cperm, dperm)):
+        dm = V.dofmap if cp is None else V.dofmap[cp]
+        gd = mesh.geom_dofmap if cp is None else mesh.geom_dofmap[cp]
+        if dp is not None:
+            dm = dp[dm]
+        m2 = w.BoxMesh(mesh.n, mesh.x, np.ascontiguousarray(gd))
+        V2 = w.FunctionSpace(m2, p, np.ascontiguousarray(dm), w.IndexMap(V.ndofs), V.lattice, structured=False)
+        op = w.StiffnessOperator(V2, p, structured=False)
+        t = time_op(op, x, y)
+        print(f"{name:24s} {t:8.3f} ms   {op.alg_bytes()/t/1e6:8.0f} GB/s alg", flush=True)
+        del op
+
+
+if __name__ == "__main__":
+    main()

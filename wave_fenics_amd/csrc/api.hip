@@ -273,14 +273,52 @@ int wf_op_create(const wf_op_desc* desc, wf_op** out)
   op->coeff = -1.0 * desc->c0 * desc->c0;   // operators.hpp:115
   int rc;
 
+  // Internal cell order: cells are summed independently, so the operator may visit
+  // them in any order.  Sorting by the smallest dof of each cell puts cells that
+  // share dofs into the same workgroup batch whatever order the caller's mesh has
+  // (a randomly ordered cfg2 mesh: 0.46 ms unsorted -> the 0.31 ms of the
+  // lexicographic order).  WF_NO_CELL_SORT=1 keeps the caller's order.
+  std::vector<int32_t> cperm(ncells);
+  for (size_t c = 0; c < ncells; ++c) cperm[c] = (int32_t)c;
+  if (!std::getenv("WF_NO_CELL_SORT") && ncells > 1) {
+    std::vector<int32_t> key(ncells);
+    for (size_t c = 0; c < ncells; ++c) key[c] = *std::min_element(desc->h_dofmap + c * nd, desc->h_dofmap + (c + 1) * nd);
+    std::stable_sort(cperm.begin(), cperm.end(), [&](int32_t a, int32_t b) { return key[a] < key[b]; });
+  }
+  bool identity_cells = true;
+  for (size_t c = 0; c < ncells && identity_cells; ++c) identity_cells = cperm[c] == (int32_t)c;
+  // permuted copies of the per-cell setup arrays (only when the order changes)
+  std::vector<int32_t> p_geom;
+  std::vector<double> p_detJ;
+  const int32_t* h_geom_dofmap = desc->h_geom_dofmap;
+  const double* h_detJ = desc->h_detJ;
+  if (!identity_cells) {
+    if (have_mesh) {
+      p_geom.resize(ncells * 8);
+      for (size_t c = 0; c < ncells; ++c) std::memcpy(&p_geom[c * 8], desc->h_geom_dofmap + (size_t)cperm[c] * 8, 8 * sizeof(int32_t));
+      h_geom_dofmap = p_geom.data();
+    }
+    if (desc->h_detJ) {
+      const size_t nqm = desc->kind == WF_OP_MASS_DENSE ? (size_t)desc->nq1 * desc->nq1 * desc->nq1 : (size_t)nd;
+      p_detJ.resize(ncells * nqm);
+      for (size_t c = 0; c < ncells; ++c) std::memcpy(&p_detJ[c * nqm], desc->h_detJ + (size_t)cperm[c] * nqm, nqm * sizeof(double));
+      h_detJ = p_detJ.data();
+    }
+  }
+
   // tensor-ordered dofmap (permute.hpp:10-27 when the caller's element ordering differs)
   {
-    std::vector<int32_t> tmp;
+    std::vector<int32_t> tmp, tmp2;
     const int32_t* src = desc->h_dofmap;
     if (desc->h_perm && ncells) {
       tmp.resize(ncells * nd);
       if ((rc = wf_reorder_dofmap(desc->ncells, nd, desc->h_perm, desc->h_dofmap, tmp.data())) != WF_OK) return rc;
       src = tmp.data();
+    }
+    if (!identity_cells) {
+      tmp2.resize(ncells * nd);
+      for (size_t c = 0; c < ncells; ++c) std::memcpy(&tmp2[c * nd], src + (size_t)cperm[c] * nd, nd * sizeof(int32_t));
+      src = tmp2.data();
     }
     if ((rc = dev_upload(&op->d_dofmap, src, ncells * nd, &op->device_bytes)) != WF_OK) return rc;
   }
@@ -296,7 +334,7 @@ int wf_op_create(const wf_op_desc* desc, wf_op** out)
   Scratch<int32_t> d_gd;
   if (have_mesh && ncells) {
     if ((rc = dev_upload(&d_x.p, desc->h_xverts, (size_t)desc->nverts * 3, nullptr)) != WF_OK) return rc;
-    if ((rc = dev_upload(&d_gd.p, desc->h_geom_dofmap, ncells * 8, nullptr)) != WF_OK) return rc;
+    if ((rc = dev_upload(&d_gd.p, h_geom_dofmap, ncells * 8, nullptr)) != WF_OK) return rc;
     if ((rc = upload_tables(P, d_pts, d_wts)) != WF_OK) return rc;
   }
 
@@ -335,9 +373,17 @@ int wf_op_create(const wf_op_desc* desc, wf_op** out)
       const size_t slab_cells = std::max<size_t>(CB, (((size_t)64 << 20) / (nd * 9 * sizeof(double))) / CB * CB);
       Scratch<double> d_G9;
       if ((rc = dev_alloc(&d_G9.p, std::min(slab_cells, std::max<size_t>(ncells, 1)) * nd * 9, nullptr)) != WF_OK) return rc;
+      std::vector<double> slab;
       for (size_t c0 = 0; c0 < ncells; c0 += slab_cells) {
         const size_t nc = std::min(slab_cells, ncells - c0);
-        WF_HIP_CHECK(hipMemcpy(d_G9.p, desc->h_G + c0 * nd * 9, nc * nd * 9 * sizeof(double), hipMemcpyHostToDevice));
+        const double* hsrc = desc->h_G + c0 * nd * 9;
+        if (!identity_cells) {
+          slab.resize(nc * nd * 9);
+          for (size_t c = 0; c < nc; ++c)
+            std::memcpy(&slab[c * nd * 9], desc->h_G + (size_t)cperm[c0 + c] * nd * 9, (size_t)nd * 9 * sizeof(double));
+          hsrc = slab.data();
+        }
+        WF_HIP_CHECK(hipMemcpy(d_G9.p, hsrc, nc * nd * 9 * sizeof(double), hipMemcpyHostToDevice));
         // slabs start on a batch boundary, so the packed destination is offset by whole batches
         if ((rc = launch_pack_G6(P, (int)nc, d_G9.p, op->d_G6blk + (c0 / CB) * CB * nd * 6, nullptr)) != WF_OK) return rc;
         WF_HIP_CHECK(hipDeviceSynchronize());
@@ -362,7 +408,7 @@ int wf_op_create(const wf_op_desc* desc, wf_op** out)
     op->nq1 = nq1;
     op->nq = nq1 * nq1 * nq1;
     if (desc->h_detJ) {
-      if ((rc = dev_upload(&op->d_detJ, desc->h_detJ, ncells * op->nq, &op->device_bytes)) != WF_OK) return rc;
+      if ((rc = dev_upload(&op->d_detJ, h_detJ, ncells * op->nq, &op->device_bytes)) != WF_OK) return rc;
     } else if (have_mesh) {
       if ((rc = dev_alloc(&op->d_detJ, ncells * nd, &op->device_bytes)) != WF_OK) return rc;
       if ((rc = launch_geometry_hex(P, desc->ncells, d_x.p, d_gd.p, d_pts.p, d_wts.p, use_fabs, 0, nullptr, nullptr,
