@@ -481,6 +481,38 @@ __global__ void k_mass_lumped(int64_t nentries, const int32_t* __restrict__ dofm
   }
 }
 
+// batch-unique form of the lumped mass (default): x once per unique dof, the
+// batch summed in LDS, one global atomic per unique dof
+__global__ __launch_bounds__(256) void k_mass_lumped_u(int ncells, int nd, int CB, const int32_t* __restrict__ uoff,
+                                                       const int32_t* __restrict__ uniq,
+                                                       const uint16_t* __restrict__ loc,
+                                                       const double* __restrict__ detJ,
+                                                       const double* __restrict__ x, double* __restrict__ y)
+{
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int t = threadIdx.x;
+  const int nbatch = (ncells + CB - 1) / CB;
+  for (int batch = blockIdx.x; batch < nbatch; batch += gridDim.x) {
+    const int u0 = uoff[batch], nu = uoff[batch + 1] - u0;
+    double* Xu = smem;
+    double* Yu = smem + nu;
+    __syncthreads();
+    for (int u = t; u < nu; u += 256) {
+      Xu[u] = x[uniq[u0 + u]];
+      Yu[u] = 0.0;
+    }
+    __syncthreads();
+    const size_t e0 = (size_t)batch * CB * nd;
+    const int ne = min(CB, ncells - batch * CB) * nd;
+    for (int p = t; p < ne; p += 256) {
+      const int l = loc[e0 + p];
+      atomicAdd(&Yu[l], Xu[l] * detJ[e0 + p]);
+    }
+    __syncthreads();
+    for (int u = t; u < nu; u += 256) unsafeAtomicAdd(&y[uniq[u0 + u]], Yu[u]);
+  }
+}
+
 // --------------------------------------------------------------------------
 // dense mass Phi^T D Phi with a tensor-product rule, sum-factorised:
 // replaces common/cuda/mass_kernel.cu:5-46 and the DGEMM pair of
@@ -491,6 +523,9 @@ __global__ void k_mass_lumped(int64_t nentries, const int32_t* __restrict__ dofm
 // --------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_mass_dense(int n, int m, int CB, int ncells,
                                                     const int32_t* __restrict__ dofmap,
+                                                    const int32_t* __restrict__ uoff,   // batch-unique lists or null
+                                                    const int32_t* __restrict__ uniq,
+                                                    const uint16_t* __restrict__ loc,
                                                     const double* __restrict__ phi1,
                                                     const double* __restrict__ detJ,
                                                     const double* __restrict__ x, double* __restrict__ y)
@@ -500,6 +535,7 @@ __global__ __launch_bounds__(256) void k_mass_dense(int n, int m, int CB, int nc
   double* A = smem;                  // ping  [CB][mx^3]
   double* B = A + CB * mx3;          // pong  [CB][mx^3]
   double* sphi = B + CB * mx3;       // [m][n]
+  double* Xu = sphi + m * n;         // [CB * nd] unique-dof tile (batch-unique form)
   const int t = threadIdx.x;
   const int nd = n * n * n, nq = m * m * m;
   for (int p = t; p < m * n; p += 256) sphi[p] = phi1[p];
@@ -508,9 +544,23 @@ __global__ __launch_bounds__(256) void k_mass_dense(int n, int m, int CB, int nc
     const int c0 = batch * CB;
     const int nc = min(CB, ncells - c0);
     __syncthreads();
-    for (int p = t; p < nc * nd; p += 256) {
-      const int c = p / nd, l = p - c * nd;
-      A[c * mx3 + l] = x[dofmap[(size_t)c0 * nd + p]];
+    int u0 = 0, nu = 0;
+    if (uoff) {
+      u0 = uoff[batch];
+      nu = uoff[batch + 1] - u0;
+      for (int u = t; u < nu; u += 256) Xu[u] = x[uniq[u0 + u]];
+      __syncthreads();
+      for (int p = t; p < nc * nd; p += 256) {
+        const int c = p / nd, l = p - c * nd;
+        A[c * mx3 + l] = Xu[loc[(size_t)c0 * nd + p]];
+      }
+      __syncthreads();
+      for (int u = t; u < nu; u += 256) Xu[u] = 0.0;
+    } else {
+      for (int p = t; p < nc * nd; p += 256) {
+        const int c = p / nd, l = p - c * nd;
+        A[c * mx3 + l] = x[dofmap[(size_t)c0 * nd + p]];
+      }
     }
     __syncthreads();
     // forward x: B[c][k][j][qi] = sum_i phi[qi][i] A[c][k][j][i]
@@ -564,7 +614,14 @@ __global__ __launch_bounds__(256) void k_mass_dense(int n, int m, int CB, int nc
       const int i = l % n, kj = l / n;
       double s = 0.0;
       for (int a = 0; a < m; ++a) s += sphi[a * n + i] * B[c * mx3 + kj * m + a];
-      unsafeAtomicAdd(&y[dofmap[(size_t)c0 * nd + p]], s);
+      if (uoff)
+        atomicAdd(&Xu[loc[(size_t)c0 * nd + p]], s);
+      else
+        unsafeAtomicAdd(&y[dofmap[(size_t)c0 * nd + p]], s);
+    }
+    if (uoff) {
+      __syncthreads();
+      for (int u = t; u < nu; u += 256) unsafeAtomicAdd(&y[uniq[u0 + u]], Xu[u]);
     }
   }
 }
@@ -740,15 +797,36 @@ int launch_mass_lumped(int64_t nentries, const int32_t* d_dofmap, const double* 
   return WF_OK;
 }
 
-int launch_mass_dense(int P, int nq1, int ncells, const int32_t* d_dofmap, const double* d_phi1,
+int launch_mass_lumped_u(int ncells, int nd, int CB, const int32_t* d_uoff, const int32_t* d_uniq,
+                         const uint16_t* d_loc, const double* d_detJ, const double* d_x, double* d_y, hipStream_t s)
+{
+  if (ncells == 0) return WF_OK;
+  const int nbatch = (ncells + CB - 1) / CB;
+  const size_t lds = (size_t)2 * CB * nd * sizeof(double);
+  hipLaunchKernelGGL(k_mass_lumped_u, dim3((unsigned)std::min(nbatch, 256 * 8)), dim3(256), lds, s, ncells, nd, CB,
+                     d_uoff, d_uniq, d_loc, d_detJ, d_x, d_y);
+  WF_LAUNCH_CHECK();
+  return WF_OK;
+}
+
+// cells per workgroup of k_mass_dense: enough that every contraction pass fills 256
+// lanes (measured: P2 >= 8, P4 2..8, P6 4)
+int mass_dense_cells_per_batch(int mx)
+{
+  int CB = std::max(1, std::min(1400 / (mx * mx * mx), 32));
+  if (const char* e = std::getenv("WF_MASS_CB")) CB = std::max(1, std::atoi(e));   // tuning hook
+  return CB;
+}
+
+int launch_mass_dense(int P, int nq1, int ncells, const int32_t* d_dofmap, const int32_t* d_uoff,
+                      const int32_t* d_uniq, const uint16_t* d_loc, int CBu, const double* d_phi1,
                       const double* d_detJ, const double* d_x, double* d_y, hipStream_t s)
 {
   if (ncells == 0) return WF_OK;
   const int n = P + 1, mx = n > nq1 ? n : nq1, mx3 = mx * mx * mx;
   // cells per workgroup: enough that every contraction pass fills 256 lanes, within ~32 KB of LDS
-  int CB = std::max(1, std::min(1400 / mx3, 32));   // measured: P2 >= 8, P4 2..8, P6 4 cells per workgroup
-  if (const char* e = std::getenv("WF_MASS_CB")) CB = std::max(1, std::atoi(e));   // tuning hook
-  const size_t lds = (size_t)(2 * CB * mx3 + nq1 * n) * sizeof(double);
+  const int CB = d_uoff ? CBu : mass_dense_cells_per_batch(mx);   // the unique lists fix the batch size
+  const size_t lds = (size_t)(2 * CB * mx3 + nq1 * n + (d_uoff ? CB * n * n * n : 0)) * sizeof(double);
   if (lds > 160 * 1024) {
     set_error("mass_dense: tables do not fit LDS");
     return WF_ERR_UNSUPPORTED;
@@ -757,8 +835,8 @@ int launch_mass_dense(int P, int nq1, int ncells, const int32_t* d_dofmap, const
   if (lds > 64 * 1024)
     WF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mass_dense), hipFuncAttributeMaxDynamicSharedMemorySize,
                         (int)lds));
-  hipLaunchKernelGGL(k_mass_dense, dim3(nb), dim3(256), lds, s, n, nq1, CB, ncells, d_dofmap, d_phi1, d_detJ, d_x,
-                     d_y);
+  hipLaunchKernelGGL(k_mass_dense, dim3(nb), dim3(256), lds, s, n, nq1, CB, ncells, d_dofmap, d_uoff, d_uniq, d_loc,
+                     d_phi1, d_detJ, d_x, d_y);
   WF_LAUNCH_CHECK();
   return WF_OK;
 }
