@@ -189,6 +189,16 @@ int wf_scatter_add(int32_t N, const int32_t* d_indices, const double* d_in, doub
 int wf_scatter_set(int32_t N, const int32_t* d_indices, const double* d_in, double* d_out, void* stream); /* out[indices[i]]  = in[i]  (VectorUpdater.hpp:141 unpack) */
 int wf_transform1(int32_t N, const double* d_in, const double* d_detJ, double* d_out, void* stream);      /* out[i] = in[i]*detJ[i]    */
 
+/* ---- a12: tall-skinny dense matmul (TSMM) ---------------------------------
+ * out[cell][n] = sum_k in[cell][k] * phi[k][n], phi row-major [K][N] on the device.
+ * Replaces the cublasDgemm pair of demo/gpu_tsmm/main.cpp:49-52 and the B / B^T
+ * products of demo/gpu_operator/main.cpp:149-155 (fp64 MFMA 16x16x4).
+ * layout 0: in[cell*K + k], out[cell*N + n]   (cell-major, demo/gpu_operator)
+ * layout 1: in[k*ncells + cell], out[n*ncells + cell]   (the column-major arrays
+ *           of demo/gpu_tsmm with lda = ldc = ncells). */
+int wf_tsmm(int layout, int64_t ncells, int K, int N, const double* d_in, const double* d_phi, double* d_out,
+            void* stream);
+
 /* ---- a15/a16: vector kernels of the RK4 loop ------------------------------
  * common/LinearGLL.hpp:17-33 (copy, axpy), :173 (fill), :182-191 (divide),
  * common/cuda/la.hpp:31-138. */

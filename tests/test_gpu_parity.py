@@ -670,3 +670,24 @@ def test_generic_ops_random_cell_order(gpu, oracle):
     y = dev(np.zeros(om.ndofs), gpu)
     w.MassOperator(V2, p, phi1, detq[cp]).apply(dev(xp, gpu), y)
     assert relerr(y.cpu().numpy()[gperm], yD) <= 1e-12
+
+
+@pytest.mark.parametrize("ncells,K,N", [(1000, 125, 125), (37, 27, 27), (513, 64, 64), (100, 8, 8), (77, 35, 192),
+                                        (50, 125, 216), (16, 3, 5)])
+def test_tsmm_vs_numpy(gpu, ncells, K, N):
+    """wf_tsmm in both array layouts (demo/gpu_operator cell-major, demo/gpu_tsmm
+    column-major with lda = ncells) against a float64 numpy product: k-ordered
+    fma chains, tolerance 1e-13 of the row magnitude."""
+    import torch
+    import wave_fenics_amd as w
+    rng = np.random.default_rng(ncells + K)
+    A = rng.uniform(-1, 1, (ncells, K))
+    B = rng.uniform(-1, 1, (K, N))
+    C = A @ B
+    scale = (np.abs(A) @ np.abs(B)).max()
+    out = torch.zeros(ncells * N, dtype=torch.float64, device=gpu)
+    w.tsmm(ncells, dev(A.reshape(-1), gpu), dev(B, gpu), out, layout=0)
+    assert np.abs(out.cpu().numpy().reshape(ncells, N) - C).max() <= 1e-13 * scale
+    out.zero_()
+    w.tsmm(ncells, dev(np.ascontiguousarray(A.T).reshape(-1), gpu), dev(B, gpu), out, layout=1)
+    assert np.abs(out.cpu().numpy().reshape(N, ncells).T - C).max() <= 1e-13 * scale

@@ -69,9 +69,32 @@ def bench_tet(dev):
             "mesh_s": round(t1 - t0, 2), "setup_s": round(t2 - t1, 2)})
 
 
+def bench_tsmm(dev):
+    # demo/gpu_tsmm/main.cpp: ndofs = 125, ncells = 100000, two products, GFLOPs = 4*ncells*nd^2/t
+    for ncells, nd in ((100000, 125), (1000000, 125), (1000000, 64), (2000000, 27)):
+        xe = torch.rand(ncells * nd, dtype=torch.float64, device=dev)
+        xq = torch.zeros_like(xe)
+        ue = torch.zeros_like(xe)
+        phi = torch.rand(nd, nd, dtype=torch.float64, device=dev)
+        for layout in (0, 1):
+            def two():
+                w.tsmm(ncells, xe, phi, xq, layout=layout)
+                w.tsmm(ncells, xq, phi, ue, layout=layout)
+            ms = timeit(two)
+            print(json.dumps({"op": f"TSMM x2 ({ncells} x {nd}) . ({nd} x {nd}), layout {layout}", "ms": round(ms, 4),
+                              "GFLOPs": round(4.0 * ncells * nd * nd / ms / 1e6, 1),
+                              "frac_of_f64_mfma_78.6TF": round(4.0 * ncells * nd * nd / ms / 1e9 / 78.6, 3),
+                              "GBs": round(4 * 8.0 * ncells * nd / ms / 1e6, 1)}), flush=True)
+
+
 def main():
     dev = torch.device("cuda", 0)
     only = sys.argv[1:] or ["stiffness", "mass", "dense", "vector"]
+    if "tsmm" in only:
+        bench_tsmm(dev)
+        only = [o for o in only if o != "tsmm"]
+        if not only:
+            return
     if "tet" in only:
         bench_tet(dev)
         only = [o for o in only if o != "tet"]

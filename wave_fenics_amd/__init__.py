@@ -12,6 +12,6 @@ from ._lib import lib, check, WavehipError  # noqa: F401
 from .box import BoxMesh, FunctionSpace, IndexMap, create_box, create_functionspace  # noqa: F401
 from .operators import (  # noqa: F401
     StiffnessOperator, MassOperator, SpectralMassOperator, MassOperatorLumped,
-    gather, scatter, transform1, tabulate_gll, tabulate_dense, precompute_geometric_data,
+    gather, scatter, transform1, tsmm, tabulate_gll, tabulate_dense, precompute_geometric_data,
 )
 from . import la  # noqa: F401

@@ -77,6 +77,7 @@ SIGNATURES = {
     "wf_scatter_add": (c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "wf_scatter_set": (c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "wf_transform1": (c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "wf_tsmm": (c_int, [c_int, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "wf_copy": (c_int, [c_int64, c_void_p, c_void_p, c_void_p]),
     "wf_fill": (c_int, [c_int64, c_double, c_void_p, c_void_p]),
     "wf_axpy": (c_int, [c_int64, c_double, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -311,3 +311,10 @@ def scatter_set(N: int, indices, inp, out, stream: int | None = None):
 def transform1(N: int, inp, detJ, out, block_size: int = 512, stream: int | None = None):
     """out[i] = in[i] * detJ[i]."""
     check(lib().wf_transform1(N, _ptr(inp), _ptr(detJ), _ptr(out), _stream(inp) if stream is None else stream))
+
+
+def tsmm(ncells: int, inp, phi, out, layout: int = 0, stream: int | None = None):
+    """out[cell][n] = sum_k in[cell][k] phi[k][n] (wf_tsmm; demo/gpu_tsmm, demo/gpu_operator DGEMMs).
+    phi: device tensor [K][N] row-major."""
+    K, N = int(phi.shape[0]), int(phi.shape[1])
+    check(lib().wf_tsmm(layout, ncells, K, N, _ptr(inp), _ptr(phi), _ptr(out), _stream(inp) if stream is None else stream))
