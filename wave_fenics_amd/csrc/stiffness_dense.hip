@@ -50,7 +50,7 @@ __global__ __launch_bounds__(64 * NW) void k_stiffness_dense(int nd, int nq, int
                                                          const int32_t* __restrict__ uoff,   // [nbatch+1]
                                                          const int32_t* __restrict__ uniq,   // unique dofs of all batches
                                                          double coeff, int do_clamp, const double* __restrict__ x,
-                                                         double* __restrict__ y)
+                                                         double* __restrict__ y, int ablate)
 {
   constexpr int NQP = 16 * QT, KP = 4 * KT + 1, NT = 64 * NW, NCB = 16 * NW;
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(64 * NW) void k_stiffness_dense(int nd, int nq, int
   for (int batch = blockIdx.x; batch < nbatch; batch += gridDim.x) {
     const int u0 = uoff[batch], nu = uoff[batch + 1] - u0;
     __syncthreads();   // previous batch's scatter has read Xu
-    for (int u = t; u < nu; u += NT) Xu[u] = x[uniq[u0 + u]];
+    for (int u = t; u < nu; u += NT) Xu[u] = (ablate & 4) ? 1.0 + u : x[uniq[u0 + u]];
     // per-lane local indices: d = 4*ks + lg of cell (wave*16 + lc)
     uint16_t loc[KT];
 #pragma unroll
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(64 * NW) void k_stiffness_dense(int nd, int nq, int
     // one 16-point slab of quadrature points at a time keeps the register
     // footprint small (3 accumulator tiles instead of 3*QT) -> more waves per SIMD
 #pragma unroll 1
-    for (int qt = 0; qt < QT; ++qt) {
+    for (int qt = 0; qt < ((ablate & 8) ? 0 : QT); ++qt) {
       // ---- W = T . U for the rows (dir, 16 qt .. 16 qt + 15) ---------------------
       double4_t W[3];
 #pragma unroll
@@ -147,7 +147,13 @@ __global__ __launch_bounds__(64 * NW) void k_stiffness_dense(int nd, int nq, int
         if (ks < KT && 4 * ks + lg < nd) atomicAdd(&Xu[loc[ks < KT ? ks : 0]], Y[dt][r]);
       }
     __syncthreads();
-    for (int u = t; u < nu; u += NT) unsafeAtomicAdd(&y[uniq[u0 + u]], Xu[u]);
+    for (int u = t; u < nu; u += NT) {
+      if (ablate & 1) {
+        if (Xu[u] == 1.2345e300) y[uniq[u0 + u]] = Xu[u];
+      } else {
+        unsafeAtomicAdd(&y[uniq[u0 + u]], Xu[u]);
+      }
+    }
   }
 }
 
@@ -291,7 +297,8 @@ static int launch_dense_t(const DenseOpData* d, double coeff, int do_clamp, cons
                                      (int)lds));
   const unsigned nb = (unsigned)std::min(d->nbatch, 256 * 2);   // persistent: the table is staged into LDS once per workgroup
   hipLaunchKernelGGL(kern, dim3(nb), dim3(64 * NW), lds, s, d->nd, d->nq, d->nbatch, d->numax, d->d_T, d->d_w, d->d_C,
-                     d->d_locT, d->d_uoff, d->d_uniq, coeff, do_clamp, d_x, d_y);
+                     d->d_locT, d->d_uoff, d->d_uniq, coeff, do_clamp, d_x, d_y,
+                     std::getenv("WF_ABLATE") ? std::atoi(std::getenv("WF_ABLATE")) : 0);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     set_error(std::string("stiffness_dense launch failed: ") + hipGetErrorString(e));
