@@ -277,3 +277,38 @@ class VectorUpdater:
 
     scatter_fwd = update_fwd
     scatter_rev = update_rev
+
+
+_SIDE_STREAMS = {}
+
+
+def overlapped_apply(op, updater: VectorUpdater, x, y, after_interface=None):
+    """y += A x on a domain-decomposed mesh with BOTH halo directions hidden:
+
+        side stream : update_fwd(x) -> apply(INTERFACE) [-> after_interface()] -> update_rev(y)
+        main stream : apply(INTERIOR)                       (reads no ghost value)
+
+    The interior part is one launch (splitting it further costs whole rounds of
+    workgroups: 3 launches took 0.36 ms against 0.26 ms for the unsplit operator at
+    cfg2), the interface cells and the two exchanges run beside it on a second HIP
+    stream and fill its tail.  Requires op.set_ghost_faces(...) == True.
+    after_interface: optional callable run on the side stream between the
+    interface cells and the reverse update (e.g. the boundary term of f1, which
+    also adds into ghost entries of y)."""
+    import torch
+    from ._lib import WF_PART_INTERFACE, WF_PART_INTERIOR
+    if not x.is_cuda:
+        raise RuntimeError("overlapped_apply needs device vectors")
+    main = torch.cuda.current_stream(x.device)
+    side = _SIDE_STREAMS.get(x.device)
+    if side is None:
+        side = _SIDE_STREAMS[x.device] = torch.cuda.Stream(device=x.device)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        updater.update_fwd(x)
+        op.apply_part(x, y, WF_PART_INTERFACE)
+        if after_interface is not None:
+            after_interface()
+        updater.update_rev(y)
+    op.apply_part(x, y, WF_PART_INTERIOR)
+    main.wait_stream(side)

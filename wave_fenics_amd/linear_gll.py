@@ -145,21 +145,17 @@ class LinearGLLOpt:
             # same operations as below, reordered so that the cells that read no ghost
             # value run while the halo of u is in flight (update_fwd_begin/_end,
             # VectorUpdater.hpp:106-143)
-            from ._lib import WF_PART_INTERFACE, WF_PART_INTERIOR_A, WF_PART_INTERIOR_B
+            from .distributed import overlapped_apply
             la.fill(self.b, 0.0)
-            self.updater.update_fwd_begin(u)
-            self.stiff_op.apply_part(u, self.b, WF_PART_INTERIOR_A)
-            self.updater.update_fwd_end(u)
+
+            def boundary():
+                self.updater.scatter_fwd(v)
+                la.boundary_apply(self.idx1, self.mG1, self.c0_ ** 2 * self.g_,
+                                  self.idx2, self.mG2, -self.c0_, v, self.b)
+
+            overlapped_apply(self.stiff_op, self.updater, u, self.b, after_interface=boundary)
             la.copy(u, self.u_n)
-            self.updater.scatter_fwd(v)
             la.copy(v, self.v_n)
-            self.stiff_op.apply_part(self.u_n, self.b, WF_PART_INTERFACE)
-            la.boundary_apply(self.idx1, self.mG1, self.c0_ ** 2 * self.g_,
-                              self.idx2, self.mG2, -self.c0_, self.v_n, self.b)
-            # reverse (add) halo of b under the second half of the interior cells
-            self.updater.update_rev_begin(self.b)
-            self.stiff_op.apply_part(self.u_n, self.b, WF_PART_INTERIOR_B)
-            self.updater.update_rev_end(self.b)
             la.pointwise_div(self.b, self.m, result)
             return
         else:
@@ -223,7 +219,7 @@ def _rk4_fused(self, startTime: float, finalTime: float, timeStep: float, max_st
     the stage-0 copies removed by pointer rotation: per stage
     K (116 B/dof at P4) + 96 B/dof instead of K + 208 B/dof.  Same arithmetic
     expressions as the unfused loop."""
-    from ._lib import WF_PART_INTERFACE, WF_PART_INTERIOR_A, WF_PART_INTERIOR_B
+    from .distributed import overlapped_apply
     t, tf, dt = startTime, finalTime, timeStep
     step = 0
     new = lambda: torch.zeros_like(self.u_n)
@@ -244,16 +240,13 @@ def _rk4_fused(self, startTime: float, finalTime: float, timeStep: float, max_st
             window = 1.0
         g = window * self.p0_ * self.w0_ / self.c0_ * math.cos(self.w0_ * tn)
         if self._split:
-            # forward halo of u under interior half A, reverse halo of b under half B
-            upd.update_fwd_begin(x_u)
-            self.stiff_op.apply_part(x_u, b, WF_PART_INTERIOR_A)
-            upd.update_fwd_end(x_u)
-            upd.scatter_fwd(x_v)
-            self.stiff_op.apply_part(x_u, b, WF_PART_INTERFACE)
-            la.boundary_apply(self.idx1, self.mG1, self.c0_ ** 2 * g, self.idx2, self.mG2, -self.c0_, x_v, b)
-            upd.update_rev_begin(b)
-            self.stiff_op.apply_part(x_u, b, WF_PART_INTERIOR_B)
-            upd.update_rev_end(b)
+            # interior cells on the main stream; halo of u, interface cells, boundary term
+            # and the reverse halo of b beside them on a second stream
+            def boundary():
+                upd.scatter_fwd(x_v)
+                la.boundary_apply(self.idx1, self.mG1, self.c0_ ** 2 * g, self.idx2, self.mG2, -self.c0_, x_v, b)
+
+            overlapped_apply(self.stiff_op, upd, x_u, b, after_interface=boundary)
             return
         if upd is not None:
             upd.scatter_fwd(x_u)
