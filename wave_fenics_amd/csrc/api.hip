@@ -26,7 +26,7 @@ struct wf_op {
   int32_t* d_uoff = nullptr;
   int32_t* d_uniq = nullptr;
   uint16_t* d_loc = nullptr;
-  int generic_unique = 0, unique_cb = 0;
+  int generic_unique = 0, unique_cb = 0, dense_square = 0;
   // work-item lists of the marching kernel: [0] interior, [1] interface, [2]/[3] the two halves of the interior
   int32_t* d_items[4] = {nullptr, nullptr, nullptr, nullptr};
   int nitems[4] = {0, 0, 0, 0};
@@ -426,10 +426,13 @@ int wf_op_create(const wf_op_desc* desc, wf_op** out)
     {
       const char* gk = std::getenv("WF_GENERIC");
       const int mx = std::max(n, nq1);
-      const int CBm = desc->kind == WF_OP_MASS_DENSE ? mass_dense_cells_per_batch(mx) : cells_per_batch(P);
+      // square tables (nq1 == P+1): column-thread kernel, batches of cells_per_batch(P)
+      const bool square = desc->kind == WF_OP_MASS_DENSE && nq1 == n && !std::getenv("WF_MASS_DENSE_GENERIC");
+      op->dense_square = square ? 1 : 0;
+      const int CBm = (desc->kind == WF_OP_MASS_DENSE && !square) ? mass_dense_cells_per_batch(mx) : cells_per_batch(P);
       // dense mass: the unique-dof tile pays off only for small elements (measured at 10 M dofs:
       // P2 0.80 -> 0.68 ms, P4 0.43 -> 0.46 ms, P6 0.34 -> 0.41 ms)
-      const bool want = desc->kind == WF_OP_MASS_LUMPED || P <= 3;
+      const bool want = desc->kind == WF_OP_MASS_LUMPED || P <= 3 || square;
       if (want && !(gk && std::strcmp(gk, "flat") == 0) && (rc = build_unique_lists(op.get(), ncells, nd, CBm)) != WF_OK)
         return rc;
     }
@@ -640,6 +643,9 @@ int wf_op_apply(wf_op* op, const double* d_x, double* d_y, void* stream)
                                     d_y, s);
       return launch_mass_lumped((int64_t)op->ncells * op->nd, op->d_dofmap, op->d_detJ, d_x, d_y, s);
     case WF_OP_MASS_DENSE:
+      if (op->dense_square && op->generic_unique)
+        return launch_mass_dense_col(op->P, op->ncells, op->d_uoff, op->d_uniq, op->d_loc, op->d_phi1, op->d_detJ, d_x, d_y,
+                                     s);
       return launch_mass_dense(op->P, op->nq1, op->ncells, op->d_dofmap, op->generic_unique ? op->d_uoff : nullptr,
                                op->d_uniq, op->d_loc, op->unique_cb, op->d_phi1, op->d_detJ, d_x, d_y, s);
   }

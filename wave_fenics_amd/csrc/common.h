@@ -80,6 +80,8 @@ int launch_mass_lumped(int64_t nentries, const int32_t* d_dofmap, const double* 
 int launch_mass_lumped_u(int ncells, int nd, int CB, const int32_t* d_uoff, const int32_t* d_uniq,
                          const uint16_t* d_loc, const double* d_detJ, const double* d_x, double* d_y, hipStream_t s);
 int mass_dense_cells_per_batch(int mx);
+int launch_mass_dense_col(int P, int ncells, const int32_t* d_uoff, const int32_t* d_uniq, const uint16_t* d_loc,
+                          const double* d_phi1, const double* d_detJ, const double* d_x, double* d_y, hipStream_t s);
 int launch_mass_dense(int P, int nq1, int ncells, const int32_t* d_dofmap, const int32_t* d_uoff,
                       const int32_t* d_uniq, const uint16_t* d_loc, int CBu, const double* d_phi1,
                       const double* d_detJ, const double* d_x, double* d_y, hipStream_t s);

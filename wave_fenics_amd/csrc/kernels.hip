@@ -627,6 +627,179 @@ __global__ __launch_bounds__(256) void k_mass_dense(int n, int m, int CB, int nc
 }
 
 // --------------------------------------------------------------------------
+// dense mass, column-thread form for square tables (nq1 == P+1: the GLL-collocated
+// rule of demo/gpu_operator_monolithic and the Gauss rule of degree 2P of
+// demo/gpu_operator): compile-time sizes, one thread per (i, j) column, the z
+// contractions in registers, x/y contractions through LDS, batch-unique
+// gather/scatter.  y += Phi^T (detJ .* (Phi x)),  Phi = phi1 (x) phi1 (x) phi1.
+// --------------------------------------------------------------------------
+template <int P>
+__global__ __launch_bounds__(256) void k_mass_dense_col(int ncells, const int32_t* __restrict__ uoff,
+                                                        const int32_t* __restrict__ uniq,
+                                                        const uint16_t* __restrict__ loc,
+                                                        const double* __restrict__ phi1,   // [n][n]: phi1[q][a]
+                                                        const double* __restrict__ detJ,   // [ncells][n^3]
+                                                        const double* __restrict__ x, double* __restrict__ y)
+{
+  constexpr int n = P + 1, n2 = n * n, nd = n * n2;
+  constexpr int CB = 256 / n2, NT = CB * n2;
+  constexpr int NFLAT = (CB * nd + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* U = smem;               // [CB][nd]
+  double* A = U + CB * nd;        // [CB][nd]; also the unique-dof tile before/after the contractions
+  double* sP = A + CB * nd;       // [n][n]
+  const int t = threadIdx.x;
+  const size_t batch = blockIdx.x;
+  const int cell0 = (int)batch * CB;
+  const bool active = t < NT;
+  const int cl = t / n2, ji = t % n2, j = ji / n, i = ji % n;
+  if (t < n * n) sP[t] = phi1[t];
+  const int u0 = uoff[batch], nu = uoff[batch + 1] - u0;
+  for (int u = t; u < nu; u += 256) A[u] = x[uniq[u0 + u]];
+  uint16_t lc[NFLAT];
+  const int nvalid = min(CB, ncells - cell0) * nd;
+#pragma unroll
+  for (int m = 0; m < NFLAT; ++m) {
+    const int pos = t + 256 * m;
+    lc[m] = pos < nvalid ? loc[(size_t)cell0 * nd + pos] : (uint16_t)0xFFFF;
+  }
+  double dj_[n];   // detJ of this thread's column (quadrature points (i, j, *)); zero for padded cells
+#pragma unroll
+  for (int k = 0; k < n; ++k) dj_[k] = (active && cell0 + cl < ncells) ? detJ[(size_t)(cell0 + cl) * nd + k * n2 + ji] : 0.0;
+  __syncthreads();
+#pragma unroll
+  for (int m = 0; m < NFLAT; ++m) {
+    const int pos = t + 256 * m;
+    if (pos < CB * nd) U[pos] = lc[m] != 0xFFFF ? A[lc[m]] : 0.0;
+  }
+  __syncthreads();
+  double* Uc = U + cl * nd;
+  double* Ac = A + cl * nd;
+  double v[n];
+  // forward x: A[k][j][qi = i] = sum_a phi[i][a] U[k][j][a]
+  if (active) {
+#pragma unroll
+    for (int k = 0; k < n; ++k) {
+      double s_ = 0.0;
+#pragma unroll
+      for (int a = 0; a < n; ++a) s_ += sP[i * n + a] * Uc[k * n2 + j * n + a];
+      v[k] = s_;
+    }
+#pragma unroll
+    for (int k = 0; k < n; ++k) Ac[k * n2 + ji] = v[k];
+  }
+  __syncthreads();
+  // forward y (thread = (qi = i, qj = j)), then z, detJ, backward z in registers
+  if (active) {
+    double vy[n];
+#pragma unroll
+    for (int k = 0; k < n; ++k) {
+      double s_ = 0.0;
+#pragma unroll
+      for (int a = 0; a < n; ++a) s_ += sP[j * n + a] * Ac[k * n2 + a * n + i];
+      vy[k] = s_;
+    }
+    double w[n];
+#pragma unroll
+    for (int q = 0; q < n; ++q) {
+      double s_ = 0.0;
+#pragma unroll
+      for (int k = 0; k < n; ++k) s_ += sP[q * n + k] * vy[k];
+      w[q] = s_ * dj_[q];
+    }
+#pragma unroll
+    for (int k = 0; k < n; ++k) {
+      double s_ = 0.0;
+#pragma unroll
+      for (int q = 0; q < n; ++q) s_ += sP[q * n + k] * w[q];
+      v[k] = s_;
+    }
+  }
+  __syncthreads();   // all reads of A (forward y) done
+  if (active) {
+#pragma unroll
+    for (int k = 0; k < n; ++k) Uc[k * n2 + ji] = v[k];   // B1[k][qj][qi]
+  }
+  __syncthreads();
+  // backward y: B2[k][j][qi = i] = sum_qj phi[qj][j] B1[k][qj][i]
+  if (active) {
+#pragma unroll
+    for (int k = 0; k < n; ++k) {
+      double s_ = 0.0;
+#pragma unroll
+      for (int q = 0; q < n; ++q) s_ += sP[q * n + j] * Uc[k * n2 + q * n + i];
+      v[k] = s_;
+    }
+#pragma unroll
+    for (int k = 0; k < n; ++k) Ac[k * n2 + ji] = v[k];
+  }
+  __syncthreads();
+  // backward x: out[k][j][i] = sum_qi phi[qi][i] B2[k][j][qi]
+  if (active) {
+#pragma unroll
+    for (int k = 0; k < n; ++k) {
+      double s_ = 0.0;
+#pragma unroll
+      for (int q = 0; q < n; ++q) s_ += sP[q * n + i] * Ac[k * n2 + j * n + q];
+      v[k] = s_;
+    }
+  }
+  __syncthreads();   // all reads of A done: A becomes the unique-dof sum tile, U the element results
+  if (active) {
+#pragma unroll
+    for (int k = 0; k < n; ++k) Uc[k * n2 + ji] = v[k];
+  }
+  for (int u = t; u < nu; u += 256) A[u] = 0.0;
+  __syncthreads();
+#pragma unroll
+  for (int m = 0; m < NFLAT; ++m) {
+    const int pos = t + 256 * m;
+    if (lc[m] != 0xFFFF) atomicAdd(&A[lc[m]], U[pos]);
+  }
+  __syncthreads();
+  for (int u = t; u < nu; u += 256) unsafeAtomicAdd(&y[uniq[u0 + u]], A[u]);
+}
+
+template <int P>
+static int launch_mass_dense_col_t(int ncells, const int32_t* d_uoff, const int32_t* d_uniq, const uint16_t* d_loc,
+                                   const double* d_phi1, const double* d_detJ, const double* d_x, double* d_y,
+                                   hipStream_t s)
+{
+  constexpr int n = P + 1, nd = n * n * n, CB = 256 / (n * n);
+  const unsigned nb = (unsigned)((ncells + CB - 1) / CB);
+  const size_t lds = (size_t)(2 * CB * nd + n * n) * sizeof(double);
+  hipLaunchKernelGGL(k_mass_dense_col<P>, dim3(nb), dim3(256), lds, s, ncells, d_uoff, d_uniq, d_loc, d_phi1, d_detJ,
+                     d_x, d_y);
+  return WF_OK;
+}
+
+int launch_mass_dense_col(int P, int ncells, const int32_t* d_uoff, const int32_t* d_uniq, const uint16_t* d_loc,
+                          const double* d_phi1, const double* d_detJ, const double* d_x, double* d_y, hipStream_t s)
+{
+  if (ncells == 0) return WF_OK;
+  int rc = WF_ERR_UNSUPPORTED;
+  switch (P) {
+    case 1: rc = launch_mass_dense_col_t<1>(ncells, d_uoff, d_uniq, d_loc, d_phi1, d_detJ, d_x, d_y, s); break;
+    case 2: rc = launch_mass_dense_col_t<2>(ncells, d_uoff, d_uniq, d_loc, d_phi1, d_detJ, d_x, d_y, s); break;
+    case 3: rc = launch_mass_dense_col_t<3>(ncells, d_uoff, d_uniq, d_loc, d_phi1, d_detJ, d_x, d_y, s); break;
+    case 4: rc = launch_mass_dense_col_t<4>(ncells, d_uoff, d_uniq, d_loc, d_phi1, d_detJ, d_x, d_y, s); break;
+    case 5: rc = launch_mass_dense_col_t<5>(ncells, d_uoff, d_uniq, d_loc, d_phi1, d_detJ, d_x, d_y, s); break;
+    case 6: rc = launch_mass_dense_col_t<6>(ncells, d_uoff, d_uniq, d_loc, d_phi1, d_detJ, d_x, d_y, s); break;
+    case 7: rc = launch_mass_dense_col_t<7>(ncells, d_uoff, d_uniq, d_loc, d_phi1, d_detJ, d_x, d_y, s); break;
+  }
+  if (rc != WF_OK) {
+    set_error("mass_dense_col: degree must be 1..7");
+    return rc;
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error(std::string("mass_dense_col launch failed: ") + hipGetErrorString(e));
+    return WF_ERR_HIP;
+  }
+  return WF_OK;
+}
+
+// --------------------------------------------------------------------------
 // launchers
 // --------------------------------------------------------------------------
 // Diagnostic ablation mask (profiling only; WF_ABLATE unset or 0 in production):
