@@ -40,11 +40,26 @@ __global__ __launch_bounds__(512) void k_tsmm(int64_t ncells, int K, int N, int 
     double4_t acc[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[nt] = double4_t{0.0, 0.0, 0.0, 0.0};
-    for (int ks = 0; ks < KT; ++ks) {
+    const int64_t c = c0 + lc;
+    // operand loads run a few k-steps ahead of the MFMAs that consume them
+    constexpr int AHEAD = 4;
+    double vbuf[AHEAD];
+#pragma unroll
+    for (int a = 0; a < AHEAD; ++a) {
+      const int k = 4 * a + lg;
+      vbuf[a] = (a < KT && k < K && c < ncells) ? (LAYOUT == 0 ? in[c * K + k] : in[(int64_t)k * ncells + c]) : 0.0;
+    }
+    for (int ks0 = 0; ks0 < KT; ks0 += AHEAD) {
+#pragma unroll
+     for (int a = 0; a < AHEAD; ++a) {
+      const int ks = ks0 + a;
+      if (ks >= KT) break;
       const int k = 4 * ks + lg;
-      const int64_t c = c0 + lc;
-      double v = 0.0;
-      if (k < K && c < ncells) v = LAYOUT == 0 ? in[c * K + k] : in[(int64_t)k * ncells + c];
+      const double v = vbuf[a];
+      {
+        const int kn = 4 * (ks + AHEAD) + lg;
+        vbuf[a] = (ks + AHEAD < KT && kn < K && c < ncells) ? (LAYOUT == 0 ? in[c * K + kn] : in[(int64_t)kn * ncells + c]) : 0.0;
+      }
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         const double p = sphi[k * NP + 16 * nt + lc];
@@ -53,6 +68,7 @@ __global__ __launch_bounds__(512) void k_tsmm(int64_t ncells, int K, int N, int 
         else
           acc[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(p, v, acc[nt], 0, 0, 0);   // D[n][cell]
       }
+     }
     }
     // D layout: row = lg + 4 r, col = lc
 #pragma unroll
