@@ -101,6 +101,14 @@ def lib():
             raise WavehipError(
                 f"{LIB_PATH} not found: build it with `python -m wave_fenics_amd.build` "
                 "(there is no CPU fallback for the operator path)")
+        # PyTorch-ROCm bundles its own HIP runtime; if libwavehip pulled in the system
+        # libamdhip64 first, torch would later start a second runtime in the same
+        # process and see no GPU.  Load torch's runtime first whenever torch is there
+        # (libwavehip then binds to the already-loaded libamdhip64 by SONAME).
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)          # AttributeError if the library lacks a declared symbol
