@@ -691,3 +691,63 @@ def test_tsmm_vs_numpy(gpu, ncells, K, N):
     out.zero_()
     w.tsmm(ncells, dev(np.ascontiguousarray(A.T).reshape(-1), gpu), dev(B, gpu), out, layout=1)
     assert np.abs(out.cpu().numpy().reshape(N, ncells).T - C).max() <= 1e-13 * scale
+
+
+def test_edge_cases_single_cell_and_empty(gpu, oracle):
+    """Smallest inputs: one cell (every kernel's partial-batch path), an operator
+    with zero local cells (a rank that owns no cell), zero-length vector kernels."""
+    import torch
+    import wave_fenics_amd as w
+    from wave_fenics_amd import la
+    for p in (1, 2, 4, 7):
+        om, mesh, V = make(oracle, (1, 1, 1), p, perturb=0.0)
+        K = oracle.StiffnessOperator(om, p)
+        M = oracle.MassOperatorCPU(om, p)
+        x = np.random.default_rng(p).uniform(-1, 1, om.ndofs)
+        yK, yM = np.zeros(om.ndofs), np.zeros(om.ndofs)
+        K(x, yK)
+        M(x, yM)
+        for structured in (True, False):
+            y = dev(np.zeros(om.ndofs), gpu)
+            w.StiffnessOperator(V, p, structured=structured)(dev(x, gpu), y)
+            assert relerr(y.cpu().numpy(), yK) <= 1e-11
+            y = dev(np.zeros(om.ndofs), gpu)
+            w.MassOperatorLumped(V, p, structured=structured)(dev(x, gpu), y)
+            assert relerr(y.cpu().numpy(), yM) <= 1e-13
+    # zero local cells
+    mesh0 = w.BoxMesh((0, 0, 0), np.zeros((1, 3)), np.zeros((0, 8), dtype=np.int32))
+    V0 = w.FunctionSpace(mesh0, 2, np.zeros((0, 27), dtype=np.int32), w.IndexMap(5), (0, 0, 0), structured=False)
+    x = torch.ones(5, dtype=torch.float64, device=gpu)
+    y = torch.full((5,), 3.0, dtype=torch.float64, device=gpu)
+    for op in (w.StiffnessOperator(V0, 2, structured=False), w.MassOperatorLumped(V0, 2, structured=False)):
+        op(x, y)
+        assert op.num_cells() == 0
+    assert bool((y == 3.0).all())
+    # zero-length vector kernels are no-ops
+    e = torch.zeros(0, dtype=torch.float64, device=gpu)
+    la.axpy(e, 1.0, e, e)
+    la.fill(e, 1.0)
+    la.copy(e, e)
+    la.pointwise_div(e, e, e)
+    assert la.inner_product(e, e) == 0.0
+
+
+def test_mass_with_element_permutation(gpu, oracle):
+    """SpectralMassOperator's reorder_dofmap path (common/cuda/spectral_mass.hpp:50-53,
+    common/permute.hpp:10-27): element-ordered dofmap + perm."""
+    import wave_fenics_amd as w
+    p, n = 3, (3, 2, 2)
+    om, mesh, V = make(oracle, n, p)
+    rng = np.random.default_rng(17)
+    eperm = rng.permutation((p + 1) ** 3).astype(np.int32)
+    inv = np.empty_like(eperm)
+    inv[eperm] = np.arange(eperm.size, dtype=np.int32)
+    dm_elem = om.dofmap[:, inv]
+    Vp = w.FunctionSpace(mesh, p, np.ascontiguousarray(dm_elem), w.IndexMap(om.ndofs), V.lattice, structured=False)
+    M = oracle.MassOperatorCPU(om, p)
+    x = rng.uniform(-1, 1, om.ndofs)
+    yref = np.zeros(om.ndofs)
+    M(x, yref)
+    y = dev(np.zeros(om.ndofs), gpu)
+    w.MassOperatorLumped(Vp, p, perm=eperm)(dev(x, gpu), y)
+    assert relerr(y.cpu().numpy(), yref) <= 1e-13
