@@ -213,8 +213,9 @@ class VectorUpdater:
         cat = lambda L: np.concatenate(L).astype(np.int32) if L else np.zeros(0, dtype=np.int32)
         self.d_indices = torch.from_numpy(cat(send_idx)).to(self.device)            # scatter_fwd_indices
         self.d_ghost_pos = torch.from_numpy(cat(recv_idx)).to(self.device)          # ghost positions
-        self.d_send_buffer = torch.zeros(self.d_indices.numel(), dtype=torch.float64, device=self.device)
-        self.d_recv_buffer = torch.zeros(self.d_ghost_pos.numel(), dtype=torch.float64, device=self.device)
+        # zero-length exchanges (a rank with no ghosts / no upper neighbour) keep a valid allocation behind the view
+        self.d_send_buffer = torch.zeros(max(self.d_indices.numel(), 1), dtype=torch.float64, device=self.device)[: self.d_indices.numel()]
+        self.d_recv_buffer = torch.zeros(max(self.d_ghost_pos.numel(), 1), dtype=torch.float64, device=self.device)[: self.d_ghost_pos.numel()]
         # a transport that cannot read device memory (gloo) is staged through the host
         self.staged = self.backend == "gloo" and self.device.type == "cuda"
         if self.staged:
