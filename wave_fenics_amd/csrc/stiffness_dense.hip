@@ -58,6 +58,8 @@ __global__ __launch_bounds__(64 * NW) void k_stiffness_dense(int nd, int nq, int
   double* sw = T + 3 * NQP * KP;    // [NQP]
   double* Xu = sw + NQP;            // [numax]  unique x values, later the unique y sums
 
+  (void)nq;
+  (void)numax;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int lc = lane & 15, lg = lane >> 4;
   for (int p = t; p < 3 * NQP * KP; p += NT) T[p] = Tg[p];
