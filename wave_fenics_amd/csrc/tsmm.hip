@@ -42,7 +42,7 @@ __global__ __launch_bounds__(512) void k_tsmm(int64_t ncells, int K, int N, int 
     for (int nt = 0; nt < NT; ++nt) acc[nt] = double4_t{0.0, 0.0, 0.0, 0.0};
     const int64_t c = c0 + lc;
     // operand loads run a few k-steps ahead of the MFMAs that consume them
-    constexpr int AHEAD = 4;
+    constexpr int AHEAD = 8;
     double vbuf[AHEAD];
 #pragma unroll
     for (int a = 0; a < AHEAD; ++a) {
