@@ -34,7 +34,9 @@ typedef enum {
   WF_ERR_INVALID = -1,     /* bad argument                                      */
   WF_ERR_UNSUPPORTED = -2, /* e.g. degree outside 1..7 (mass.hpp:91-92 throws)  */
   WF_ERR_HIP = -3,         /* a HIP runtime call failed (array.hpp:15-17 throws) */
-  WF_ERR_NODEVICE = -4     /* fewer devices than requested (utils.hpp:30-34)     */
+  WF_ERR_NODEVICE = -4,    /* fewer devices than requested (utils.hpp:30-34)     */
+  WF_ERR_COMM = -5         /* RCCL missing or a communication call failed
+                              (the reference asserts on MPI status, VectorUpdater.hpp:120) */
 } wf_status;
 
 typedef struct wf_op wf_op;
@@ -225,6 +227,76 @@ int wf_rk4_stage(int64_t n, double bdt, double adt_next, int has_next, double* d
 int wf_boundary_apply(int32_t n1, const int32_t* d_idx1, const double* d_m1, double s1,
                       int32_t n2, const int32_t* d_idx2, const double* d_m2, double s2,
                       const double* d_v, double* d_b, void* stream);
+
+/* ---- a14: ghost exchange over RCCL ----------------------------------------
+ * demo/gpu_scatter_mpi/VectorUpdater.hpp:21-230 (GPU pack + CUDA-aware MPI per
+ * IndexMap neighbour) and la::Vector::scatter_fwd / scatter_rev(add) of
+ * common/LinearGLL.hpp:110,127,164-176.  One process per GPU; the transport is a
+ * grouped ncclSend/ncclRecv per neighbour (RCCL over xGMI) enqueued on a HIP
+ * stream -- no host synchronisation anywhere.  librccl is bound at run time.
+ *
+ * Communicator: rank 0 calls wf_comm_unique_id, the launcher distributes the 128
+ * bytes (MPI_Bcast, torch.distributed, or the file rendezvous below), every rank
+ * calls wf_comm_create after wf_set_device. */
+#define WF_COMM_ID_BYTES 128
+typedef struct wf_comm wf_comm;
+typedef struct wf_updater wf_updater;
+typedef enum { WF_SUM = 0, WF_MAX = 1 } wf_reduce_op;
+
+int wf_comm_unique_id(char* id /* [WF_COMM_ID_BYTES] */);
+int wf_comm_create(const char* id, int rank, int nranks, wf_comm** out);
+/* rank 0 publishes the id in `path` (unique per job), the others poll up to timeout_s */
+int wf_comm_create_from_file(const char* path, int rank, int nranks, double timeout_s, wf_comm** out);
+int wf_comm_info(const wf_comm* comm, int* rank, int* nranks, int* rccl_version); /* outputs may be NULL */
+/* MPI_Allreduce of demo/gpu_cg/CUDA/cg.hpp:21 on device scalars / arrays (in place allowed) */
+int wf_comm_allreduce(wf_comm* comm, int op, int64_t count, const double* d_in, double* d_out, void* stream);
+int wf_comm_barrier(wf_comm* comm, void* stream);   /* all ranks reached this point; synchronises `stream` */
+int wf_comm_destroy(wf_comm* comm);
+
+/* The IndexMap data VectorUpdater's constructor reads (VectorUpdater.hpp:31-98).
+ * Segment i of send_indices [send_offsets[i], send_offsets[i+1]) lists the OWNED
+ * local dofs that send_neighbors[i] holds as ghosts (scatter_fwd_indices);
+ * segment i of ghost_positions lists the local positions of the ghosts owned by
+ * recv_neighbors[i] in the order that neighbour sends them.  Positions index the
+ * whole local array (a DOLFINx caller passes size_local + ghost index).  A rank may
+ * be its own neighbour (periodic partition). */
+typedef enum {
+  WF_UPDATER_DEFAULT = 0,
+  WF_UPDATER_INLINE = 1   /* enqueue the exchange on the caller's stream instead of the
+                             updater's communication stream (begin/end then do not overlap) */
+} wf_updater_flags;
+typedef struct {
+  int ndofs;                          /* local array length: owned + ghosts               */
+  int num_send_neighbors;
+  const int* send_neighbors;          /* [num_send_neighbors] ranks                        */
+  const int32_t* send_offsets;        /* [num_send_neighbors + 1], send_offsets[0] = 0     */
+  const int32_t* send_indices;        /* [send_offsets[last]]                              */
+  int num_recv_neighbors;
+  const int* recv_neighbors;
+  const int32_t* recv_offsets;        /* [num_recv_neighbors + 1]                          */
+  const int32_t* ghost_positions;     /* [recv_offsets[last]]                              */
+  int flags;                          /* wf_updater_flags                                  */
+} wf_updater_desc;
+int wf_updater_create(wf_comm* comm, const wf_updater_desc* desc, wf_updater** out);
+/* update_fwd: owners -> ghosts (VectorUpdater.hpp:106-152).  begin packs on `stream`
+ * and posts the exchange on the updater's own stream; work enqueued on `stream`
+ * between begin and end overlaps with it; end makes `stream` wait and unpacks.
+ * One exchange may be in flight per updater. */
+int wf_updater_fwd_begin(wf_updater* u, const double* d_x, void* stream);
+int wf_updater_fwd_end(wf_updater* u, double* d_x, void* stream);
+int wf_updater_fwd(wf_updater* u, double* d_x, void* stream);
+/* update_rev: ghosts -> owners, accumulating (VectorUpdater.hpp:157-208) */
+int wf_updater_rev_begin(wf_updater* u, const double* d_x, void* stream);
+int wf_updater_rev_end(wf_updater* u, double* d_x, void* stream);
+int wf_updater_rev(wf_updater* u, double* d_x, void* stream);
+int wf_updater_info(const wf_updater* u, int* num_send, int* num_recv, int* num_send_neighbors, int* num_recv_neighbors);
+int wf_updater_destroy(wf_updater* u);
+
+/* y += A x on a domain-decomposed box mesh (LinearGLL.hpp:164-176 = scatter_fwd(x);
+ * apply; scatter_rev(y)) with both halo directions hidden: the updater's side stream
+ * runs update_fwd(x) -> apply(INTERFACE) -> update_rev(y) beside apply(INTERIOR) on
+ * `stream`, which continues after both.  Needs wf_op_set_ghost_faces. */
+int wf_op_apply_overlapped(wf_op* op, wf_updater* u, double* d_x, double* d_y, void* stream);
 
 #ifdef __cplusplus
 }

@@ -14,6 +14,7 @@
 #pragma once
 
 #include <cstdint>
+#include <cstdlib>
 #include <map>
 #include <memory>
 #include <stdexcept>
@@ -231,6 +232,124 @@ public:
   {
     check(wf_op_create_box(WF_OP_STIFFNESS, degree, nx, ny, nz, xverts, c0, WF_FLAG_NONE, &_op));
   }
+};
+
+// ---- communicator + VectorUpdater (demo/gpu_scatter_mpi/VectorUpdater.hpp) ----
+/// RCCL communicator behind the C ABI.  The reference's launcher is mpirun; a
+/// launcher that exports RANK / WORLD_SIZE / LOCAL_RANK (torchrun --no-python,
+/// a shell loop, SLURM) works with from_env(), which meets through a file.
+class Comm {
+public:
+  Comm(const char* id, int rank, int nranks) { check(wf_comm_create(id, rank, nranks, &_c)); }
+  Comm(const std::string& rendezvous_file, int rank, int nranks, double timeout_s = 120.0)
+  {
+    check(wf_comm_create_from_file(rendezvous_file.c_str(), rank, nranks, timeout_s, &_c));
+  }
+  Comm(const Comm&) = delete;
+  Comm& operator=(const Comm&) = delete;
+  ~Comm() { wf_comm_destroy(_c); }
+
+  static int env_int(const char* name, int dflt)
+  {
+    const char* e = std::getenv(name);
+    return e ? std::atoi(e) : dflt;
+  }
+  /// One rank per process: device LOCAL_RANK, rendezvous file $WF_COMM_FILE or
+  /// /tmp/wavehip_comm_$MASTER_PORT.  Calls set_device.
+  static std::unique_ptr<Comm> from_env()
+  {
+    const int rank = env_int("RANK", 0), size = env_int("WORLD_SIZE", 1);
+    set_device(env_int("LOCAL_RANK", rank));
+    const char* f = std::getenv("WF_COMM_FILE");
+    std::string path = f ? f : std::string("/tmp/wavehip_comm_") + std::to_string(env_int("MASTER_PORT", 29500));
+    return std::make_unique<Comm>(path, rank, size);
+  }
+  int rank() const
+  {
+    int r = 0;
+    check(wf_comm_info(_c, &r, nullptr, nullptr));
+    return r;
+  }
+  int size() const
+  {
+    int n = 1;
+    check(wf_comm_info(_c, nullptr, &n, nullptr));
+    return n;
+  }
+  /// MPI_Allreduce on device data (demo/gpu_cg/CUDA/cg.hpp:21)
+  void allreduce(const double* d_in, double* d_out, std::int64_t count, int op = WF_SUM, void* stream = nullptr)
+  {
+    check(wf_comm_allreduce(_c, op, count, d_in, d_out, stream));
+  }
+  void barrier(void* stream = nullptr) { check(wf_comm_barrier(_c, stream)); }
+  wf_comm* handle() const { return _c; }
+
+private:
+  wf_comm* _c = nullptr;
+};
+
+/// The IndexMap data the reference's VectorUpdater constructor extracts
+/// (VectorUpdater.hpp:31-98): neighbours, displacements, scatter_fwd_indices and
+/// ghost positions.  A DOLFINx caller fills it from
+/// index_map->scatter_fwd_indices() / scatter_fwd_ghost_positions().
+struct GhostLists {
+  std::int32_t ndofs = 0;                       // size_local + num_ghosts
+  std::vector<int> send_neighbors, recv_neighbors;
+  std::vector<std::int32_t> send_offsets{0}, recv_offsets{0};
+  std::vector<std::int32_t> send_indices;       // owned local dofs, per send neighbour
+  std::vector<std::int32_t> ghost_positions;    // local positions of the ghosts, per recv neighbour
+  bool empty() const { return send_neighbors.empty() && recv_neighbors.empty(); }
+};
+
+/// VectorUpdater<T, AllocatorT> -- demo/gpu_scatter_mpi/VectorUpdater.hpp:21-230.
+/// Same method names; vectors are anything with array()/mutable_array() or raw
+/// device pointers.  All calls are stream-ordered (no host synchronisation).
+template <typename T>
+class VectorUpdater {
+  static_assert(sizeof(T) == sizeof(double), "fp64 only");
+
+public:
+  VectorUpdater(Comm* comm, const GhostLists& g, int flags = WF_UPDATER_DEFAULT)
+  {
+    wf_updater_desc d{};
+    d.ndofs = g.ndofs;
+    d.num_send_neighbors = (int)g.send_neighbors.size();
+    d.send_neighbors = g.send_neighbors.data();
+    d.send_offsets = g.send_offsets.data();
+    d.send_indices = g.send_indices.data();
+    d.num_recv_neighbors = (int)g.recv_neighbors.size();
+    d.recv_neighbors = g.recv_neighbors.data();
+    d.recv_offsets = g.recv_offsets.data();
+    d.ghost_positions = g.ghost_positions.data();
+    d.flags = flags;
+    check(wf_updater_create(comm ? comm->handle() : nullptr, &d, &_u));
+  }
+  VectorUpdater(const VectorUpdater&) = delete;
+  VectorUpdater& operator=(const VectorUpdater&) = delete;
+  ~VectorUpdater() { wf_updater_destroy(_u); }
+
+  void update_fwd_begin(const T* x, void* stream = nullptr) { check(wf_updater_fwd_begin(_u, x, stream)); }
+  void update_fwd_end(T* x, void* stream = nullptr) { check(wf_updater_fwd_end(_u, x, stream)); }
+  void update_fwd(T* x, void* stream = nullptr) { check(wf_updater_fwd(_u, x, stream)); }
+  void update_rev_begin(const T* x, void* stream = nullptr) { check(wf_updater_rev_begin(_u, x, stream)); }
+  void update_rev_end(T* x, void* stream = nullptr) { check(wf_updater_rev_end(_u, x, stream)); }
+  void update_rev(T* x, void* stream = nullptr) { check(wf_updater_rev(_u, x, stream)); }
+  template <typename Vector>
+  void update_fwd_begin(const Vector& x) { update_fwd_begin(x.array().data()); }
+  template <typename Vector>
+  void update_fwd_end(Vector& x) { update_fwd_end(x.mutable_array().data()); }
+  template <typename Vector>
+  void update_fwd(Vector& x) { update_fwd(x.mutable_array().data()); }
+  template <typename Vector>
+  void update_rev_begin(const Vector& x) { update_rev_begin(x.array().data()); }
+  template <typename Vector>
+  void update_rev_end(Vector& x) { update_rev_end(x.mutable_array().data()); }
+  template <typename Vector>
+  void update_rev(Vector& x) { update_rev(x.mutable_array().data()); }
+  wf_updater* handle() const { return _u; }
+
+private:
+  wf_updater* _u = nullptr;
 };
 
 // ---- linalg:: (common/cuda/la.hpp:31-138) and kernels:: (LinearGLL.hpp:15-35)

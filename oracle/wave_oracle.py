@@ -258,6 +258,7 @@ class BoxMesh:
     ndofs: int
     lattice: tuple      # dof lattice (NX, NY, NZ)
     facet_tags: dict = field(default_factory=dict)
+    periodic: tuple = (False, False, False)
 
     @property
     def ncells(self):
@@ -298,6 +299,24 @@ def create_box(n, p: int, lo=(0.0, 0.0, 0.0), hi=(1.0, 1.0, 1.0), perturb: float
     dm = ((p * cx[:, None] + i[None, :])
           + NX * ((p * cy[:, None] + j[None, :]) + NY * (p * cz[:, None] + k[None, :])))
     return BoxMesh((nx, ny, nz), p, x, gd, dm.astype(np.int32), NX * NY * NZ, (NX, NY, NZ))
+
+
+def make_periodic(mesh: BoxMesh, periodic) -> np.ndarray:
+    """Identify the upper face of every axis in `periodic` with the lower one: the
+    dofmap is renumbered onto the reduced lattice (upper-plane dofs take the number
+    of their lower-plane image), exterior facets on those axes disappear
+    (box_facets).  Test infrastructure for the ghost-exchange parity tests: a
+    periodic operator is what local apply + self/neighbour exchange must equal.
+    Returns the map old lattice index -> new dof number."""
+    NX, NY, NZ = mesh.lattice
+    per = tuple(bool(v) for v in periodic)
+    K, J, I = np.meshgrid(np.arange(NZ), np.arange(NY), np.arange(NX), indexing="ij")
+    RX, RY, RZ = (NX - 1 if per[0] else NX), (NY - 1 if per[1] else NY), (NZ - 1 if per[2] else NZ)
+    new = ((I % RX) + RX * ((J % RY) + RY * (K % RZ))).reshape(-1)
+    mesh.dofmap = new[mesh.dofmap].astype(np.int32)
+    mesh.ndofs = RX * RY * RZ
+    mesh.periodic = per
+    return new
 
 
 def cmap_tabulate(X: np.ndarray):
@@ -468,6 +487,8 @@ def box_facets(mesh: BoxMesh):
     cz, cy, cx = np.meshgrid(np.arange(nz), np.arange(ny), np.arange(nx), indexing="ij")
     cid = (cx + nx * (cy + ny * cz))
     for axis, (cc, nn) in enumerate(((cx, nx), (cy, ny), (cz, nz))):
+        if mesh.periodic[axis]:
+            continue
         for side in (0, 1):
             sel = cid[cc == (0 if side == 0 else nn - 1)].reshape(-1)
             tag = 1 if (axis == 0 and side == 0) else 2

@@ -36,12 +36,13 @@ def local_to_global(part):
     p = part.degree
     NX, NY, NZ = part.V.lattice
     gn = [part.procs[a] * part.n_local[a] for a in range(3)]
-    GX, GY = p * gn[0] + 1, p * gn[1] + 1
+    per = getattr(part, "periodic", (False, False, False))
+    G = [p * gn[a] + (0 if per[a] else 1) for a in range(3)]     # periodic axes: the upper plane is the lower one
     K, J, I = np.meshgrid(np.arange(NZ), np.arange(NY), np.arange(NX), indexing="ij")
-    Ig = I + p * part.n_local[0] * part.coords[0]
-    Jg = J + p * part.n_local[1] * part.coords[1]
-    Kg = K + p * part.n_local[2] * part.coords[2]
-    return (Ig + GX * (Jg + GY * Kg)).reshape(-1)
+    Ig = (I + p * part.n_local[0] * part.coords[0]) % G[0]
+    Jg = (J + p * part.n_local[1] * part.coords[1]) % G[1]
+    Kg = (K + p * part.n_local[2] * part.coords[2]) % G[2]
+    return (Ig + G[0] * (Jg + G[1] * Kg)).reshape(-1)
 
 
 def init_pg(rank, world, port, backend="gloo"):

@@ -48,6 +48,34 @@ def test_partition_lists_cover_ghosts():
             assert all(len(pt.send_fwd) + len(pt.recv_fwd) <= 7 for pt in parts) and len(parts[0].send_fwd) == 7
 
 
+def test_periodic_partition_lists():
+    """Periodic partitions (a rank may be its own neighbour, several directions may
+    lead to the same neighbour): every ghost is received exactly once, the k-th entry
+    a rank sends to a neighbour is the k-th entry that neighbour receives from it."""
+    from dist_helpers import local_to_global
+    from wave_fenics_amd.distributed import create_distributed_box
+    cases = [(1, (2, 2, 2), 2, (True, False, False)), (1, (2, 1, 2), 3, (True, True, True)),
+             (2, (2, 2, 1), 2, (True, True, False)), (4, (1, 2, 2), 2, (True, True, True)),
+             (8, (1, 1, 1), 2, (True, False, True)), (2, (2, 2, 2), 1, (False, True, False))]
+    for world, n, p, per in cases:
+        parts = [create_distributed_box(n, p, world, r, periodic=per) for r in range(world)]
+        assert sum(pt.num_owned for pt in parts) == parts[0].size_global
+        owned_global = []
+        for r, part in enumerate(parts):
+            l2g = local_to_global(part)
+            ghost = ~part.owned_mask()
+            recv_all = np.concatenate(list(part.recv_fwd.values())) if part.recv_fwd else np.zeros(0, int)
+            assert np.array_equal(np.sort(recv_all), np.nonzero(ghost)[0])
+            owned_global.append(l2g[part.owned_mask()])
+            for nb, idx in part.recv_fwd.items():
+                other = parts[nb]
+                assert r in other.send_fwd and other.send_fwd[r].size == idx.size
+                assert np.array_equal(local_to_global(other)[other.send_fwd[r]], l2g[idx])
+                assert other.owned_mask()[other.send_fwd[r]].all()
+        allg = np.concatenate(owned_global)
+        assert np.array_equal(np.sort(allg), np.arange(parts[0].size_global))      # every global dof owned exactly once
+
+
 def _worker(rank, world, port, n, p, perturb, q):
     try:
         import torch

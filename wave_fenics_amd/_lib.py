@@ -43,6 +43,20 @@ class OpInfo(ctypes.Structure):
     ]
 
 
+class UpdaterDesc(ctypes.Structure):
+    _fields_ = [
+        ("ndofs", c_int),
+        ("num_send_neighbors", c_int), ("send_neighbors", POINTER(c_int)),
+        ("send_offsets", POINTER(c_int32)), ("send_indices", POINTER(c_int32)),
+        ("num_recv_neighbors", c_int), ("recv_neighbors", POINTER(c_int)),
+        ("recv_offsets", POINTER(c_int32)), ("ghost_positions", POINTER(c_int32)),
+        ("flags", c_int),
+    ]
+
+
+WF_COMM_ID_BYTES = 128
+WF_SUM, WF_MAX = 0, 1
+WF_UPDATER_DEFAULT, WF_UPDATER_INLINE = 0, 1
 WF_OP_STIFFNESS, WF_OP_MASS_LUMPED, WF_OP_MASS_DENSE = 0, 1, 2
 WF_FLAG_NONE, WF_FLAG_NO_FABS, WF_FLAG_NO_CLAMP = 0, 1, 2
 WF_PART_ALL, WF_PART_INTERIOR, WF_PART_INTERFACE, WF_PART_INTERIOR_A, WF_PART_INTERIOR_B = 0, 1, 2, 3, 4
@@ -86,6 +100,23 @@ SIGNATURES = {
     "wf_pointwise_mult_add": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "wf_dot": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "wf_rk4_stage": (c_int, [c_int64, c_double, c_double, c_int] + [c_void_p] * 12),
+    "wf_comm_unique_id": (c_int, [c_char_p]),
+    "wf_comm_create": (c_int, [c_char_p, c_int, c_int, POINTER(c_void_p)]),
+    "wf_comm_create_from_file": (c_int, [c_char_p, c_int, c_int, c_double, POINTER(c_void_p)]),
+    "wf_comm_info": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
+    "wf_comm_allreduce": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_void_p, c_void_p]),
+    "wf_comm_barrier": (c_int, [c_void_p, c_void_p]),
+    "wf_comm_destroy": (c_int, [c_void_p]),
+    "wf_updater_create": (c_int, [c_void_p, POINTER(UpdaterDesc), POINTER(c_void_p)]),
+    "wf_updater_fwd_begin": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "wf_updater_fwd_end": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "wf_updater_fwd": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "wf_updater_rev_begin": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "wf_updater_rev_end": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "wf_updater_rev": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "wf_updater_info": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
+    "wf_updater_destroy": (c_int, [c_void_p]),
+    "wf_op_apply_overlapped": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "wf_boundary_apply": (c_int, [c_int32, c_void_p, c_void_p, c_double, c_int32, c_void_p, c_void_p, c_double,
                                   c_void_p, c_void_p, c_void_p]),
 }

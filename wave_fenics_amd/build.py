@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libwavehip.so")
-SOURCES = ["tables.cpp", "kernels.hip", "stiffness_march.hip", "stiffness_dense.hip", "tsmm.hip", "vector_kernels.hip", "api.hip"]
+SOURCES = ["tables.cpp", "kernels.hip", "stiffness_march.hip", "stiffness_dense.hip", "tsmm.hip", "vector_kernels.hip", "comm.hip", "api.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "stiffness_core.h"),
            os.path.join(ROOT, "include", "wavehip.h")]
 
@@ -29,19 +29,27 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _compile(src: str, force: bool, verbose: bool) -> str:
+    obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
+    path = os.path.join(CSRC, src)
+    deps = [path] + HEADERS
+    if not force and os.path.exists(obj) and all(os.path.getmtime(d) <= os.path.getmtime(obj) for d in deps):
+        return obj
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
+           "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-c", path, "-o", obj]
+    if verbose:
+        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+    subprocess.check_call(cmd)
+    return obj
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB
-    objs = []
-    for src in SOURCES:
-        obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
-        cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
-               "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-c", os.path.join(CSRC, src), "-o", obj]
-        if verbose:
-            cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
-        subprocess.check_call(cmd)
-        objs.append(obj)
-    subprocess.check_call([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=1 if verbose else min(8, len(SOURCES))) as ex:
+        objs = list(ex.map(lambda s: _compile(s, force, verbose), SOURCES))
+    subprocess.check_call([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"])
     return LIB
 
 

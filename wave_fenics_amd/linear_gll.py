@@ -10,7 +10,10 @@ is applied in its diagonal GLL form by wf_boundary_apply.
 
 Ghost exchange: `updater` (a VectorUpdater) supplies scatter_fwd / scatter_rev
 where the reference calls la::Vector::scatter_fwd / scatter_rev(add)
-(LinearGLL.hpp:110,127,164,167,176,284-285); None on one rank."""
+(LinearGLL.hpp:110,127,164,176,284-285); None on one rank.  The forward update
+of v inside f1 (LinearGLL.hpp:167) is not needed here: the boundary term is
+applied by the owner of each boundary dof with the fully assembled facet mass
+(distributed.owned_boundary), so no ghost value of v is ever read."""
 from __future__ import annotations
 
 import math
@@ -108,8 +111,13 @@ class LinearGLLOpt:
         if boundary is None:
             if tags is None:
                 tags = {0: 1, 1: 2, 2: 2, 3: 2, 4: 2, 5: 2}
-            i1, m1 = facet_lumped_mass(V, tags, 1)
-            i2, m2 = facet_lumped_mass(V, tags, 2)
+            if self.updater is not None:
+                from .distributed import owned_boundary
+                i1, m1 = owned_boundary(self.updater, V, tags, 1, self.device)
+                i2, m2 = owned_boundary(self.updater, V, tags, 2, self.device)
+            else:
+                i1, m1 = facet_lumped_mass(V, tags, 1)
+                i2, m2 = facet_lumped_mass(V, tags, 2)
         else:
             (i1, m1), (i2, m2) = boundary
         td = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(self.device, dtype=dt)
@@ -147,13 +155,9 @@ class LinearGLLOpt:
             # VectorUpdater.hpp:106-143)
             from .distributed import overlapped_apply
             la.fill(self.b, 0.0)
-
-            def boundary():
-                self.updater.scatter_fwd(v)
-                la.boundary_apply(self.idx1, self.mG1, self.c0_ ** 2 * self.g_,
-                                  self.idx2, self.mG2, -self.c0_, v, self.b)
-
-            overlapped_apply(self.stiff_op, self.updater, u, self.b, after_interface=boundary)
+            overlapped_apply(self.stiff_op, self.updater, u, self.b)
+            la.boundary_apply(self.idx1, self.mG1, self.c0_ ** 2 * self.g_,
+                              self.idx2, self.mG2, -self.c0_, v, self.b)
             la.copy(u, self.u_n)
             la.copy(v, self.v_n)
             la.pointwise_div(self.b, self.m, result)
@@ -162,8 +166,6 @@ class LinearGLLOpt:
             if self.updater is not None:
                 self.updater.scatter_fwd(u)
             la.copy(u, self.u_n)
-            if self.updater is not None:
-                self.updater.scatter_fwd(v)
             la.copy(v, self.v_n)
             la.fill(self.b, 0.0)
             self.stiff_op(self.u_n, self.b)
@@ -240,17 +242,13 @@ def _rk4_fused(self, startTime: float, finalTime: float, timeStep: float, max_st
             window = 1.0
         g = window * self.p0_ * self.w0_ / self.c0_ * math.cos(self.w0_ * tn)
         if self._split:
-            # interior cells on the main stream; halo of u, interface cells, boundary term
-            # and the reverse halo of b beside them on a second stream
-            def boundary():
-                upd.scatter_fwd(x_v)
-                la.boundary_apply(self.idx1, self.mG1, self.c0_ ** 2 * g, self.idx2, self.mG2, -self.c0_, x_v, b)
-
-            overlapped_apply(self.stiff_op, upd, x_u, b, after_interface=boundary)
+            # interior cells on the main stream; halo of u, interface cells and the
+            # reverse halo of b beside them on a second stream
+            overlapped_apply(self.stiff_op, upd, x_u, b)
+            la.boundary_apply(self.idx1, self.mG1, self.c0_ ** 2 * g, self.idx2, self.mG2, -self.c0_, x_v, b)
             return
         if upd is not None:
             upd.scatter_fwd(x_u)
-            upd.scatter_fwd(x_v)
         self.stiff_op(x_u, b)
         la.boundary_apply(self.idx1, self.mG1, self.c0_ ** 2 * g, self.idx2, self.mG2, -self.c0_, x_v, b)
         if upd is not None:
