@@ -214,8 +214,8 @@ int wf_dot(int64_t n, const double* d_x, const double* d_y, double* d_result, vo
 
 /* Fused vector algebra between two stiffness applies of the RK4 loop
  * (common/LinearGLL.hpp:182-191, :260, :264-265 and the next stage's :250-254):
- *   kv = b/m; ku = vn; u = ku*bdt + u_read; v = kv*bdt + v_read;
- *   if has_next: un = ku*adt_next + u0; vn_next = kv*adt_next + v0; b = 0.
+ *   kv = b/m; ku = vn; u = ku*bdt + u_read; v = kv*bdt + v_read; b = 0 (LinearGLL.hpp:173);
+ *   if has_next: un = ku*adt_next + u0; vn_next = kv*adt_next + v0.
  * u_read/v_read may alias u/v; vn_next must not alias vn. */
 int wf_rk4_stage(int64_t n, double bdt, double adt_next, int has_next, double* d_b, const double* d_m,
                  const double* d_vn, const double* d_u_read, const double* d_v_read, double* d_u, double* d_v,

@@ -141,6 +141,7 @@ public:
   template <typename Vector>
   void operator()(const Vector& x, Vector& y) { apply(x, y); }
   void apply(const double* d_x, double* d_y, void* stream = nullptr) { check(wf_op_apply(_op, d_x, d_y, stream)); }
+  wf_op* handle() const { return _op; }
 
 protected:
   wf_op_info_t info() const

@@ -5,8 +5,10 @@
 // (demo/cpu_planar3d/forms.ufl:19-24).
 #pragma once
 
+#include <algorithm>
 #include <array>
 #include <cmath>
+#include <functional>
 #include <cstdint>
 #include <map>
 #include <vector>
@@ -168,6 +170,162 @@ facet_lumped_mass(const BoxSpace& V, const std::map<int, int>& tag_of_face, int 
     out.second.push_back(kv.second);
   }
   return out;
+}
+
+// ---- domain decomposition (idea of demo/gpu_cg/mesh.hpp:37-63) -------
+/// Split nproc into px >= py >= pz, as balanced as possible (1, 2x1x1, 2x2x1, 2x2x2).
+inline std::array<int, 3> decompose3d(int nproc)
+{
+  std::array<int, 3> best{nproc, 1, 1};
+  long best_score = -1;
+  for (int a = 1; a <= nproc; ++a) {
+    if (nproc % a) continue;
+    for (int b = 1; b <= nproc / a; ++b) {
+      if ((nproc / a) % b) continue;
+      std::array<int, 3> d{a, b, nproc / a / b};
+      std::sort(d.begin(), d.end(), std::greater<int>());
+      const long score = (long)(d[0] - d[2]) * 100000 + d[0];
+      if (best_score < 0 || score < best_score) {
+        best_score = score;
+        best = d;
+      }
+    }
+  }
+  return best;
+}
+/// rank = rz + pz*(ry + py*rx)  (compute_cartesian_indices, z fastest)
+inline std::array<int, 3> rank_coords(int rank, const std::array<int, 3>& procs)
+{
+  return {rank / (procs[1] * procs[2]), (rank / procs[2]) % procs[1], rank % procs[2]};
+}
+inline int coords_rank(const std::array<int, 3>& c, const std::array<int, 3>& procs)
+{
+  return c[2] + procs[2] * (c[1] + procs[1] * c[0]);
+}
+
+/// One rank's part of a Cartesian partition of the box: local mesh and space, the
+/// ghost lists for VectorUpdater, the owned/ghost split.  A lattice point shared by
+/// several ranks belongs to the lowest one, so the ghosts of a rank are its lower
+/// lattice planes; local vectors keep the lattice numbering (ghosts interleaved).
+struct BoxPartition {
+  std::array<int, 3> procs{1, 1, 1}, coords{0, 0, 0}, n_local{};
+  std::array<bool, 3> periodic{false, false, false};
+  std::array<int, 3> owned_lo{0, 0, 0};       // first owned lattice index per axis
+  int rank = 0, degree = 0;
+  std::int64_t size_global = 0;
+  BoxMesh mesh;
+  BoxSpace V;
+  GhostLists ghosts;
+
+  std::int64_t num_owned() const
+  {
+    return (std::int64_t)(V.lattice[0] - owned_lo[0]) * (V.lattice[1] - owned_lo[1]) * (V.lattice[2] - owned_lo[2]);
+  }
+  bool owned(std::int32_t dof) const
+  {
+    const int I = dof % V.lattice[0], J = (dof / V.lattice[0]) % V.lattice[1], K = dof / (V.lattice[0] * V.lattice[1]);
+    return I >= owned_lo[0] && J >= owned_lo[1] && K >= owned_lo[2];
+  }
+  /// facet tags under the cfg1 convention: global face x = lo -> 1, other global faces -> 2
+  std::map<int, int> boundary_tags() const
+  {
+    std::map<int, int> tags;
+    for (int a = 0; a < 3; ++a) {
+      if (periodic[a]) continue;
+      if (coords[a] == 0) tags[2 * a] = a == 0 ? 1 : 2;
+      if (coords[a] == procs[a] - 1) tags[2 * a + 1] = 2;
+    }
+    return tags;
+  }
+};
+
+/// Weak-scaled box: n cells per direction PER RANK, global mesh (px nx, py ny, pz nz)
+/// cells on [lo, hi].  periodic[a] identifies the upper face of axis a with the lower
+/// one (a rank can then be its own neighbour).  Returned by pointer: V refers to mesh.
+inline std::unique_ptr<BoxPartition> create_distributed_box(std::array<int, 3> n, int degree, int nproc, int rank,
+                                                            std::array<double, 3> lo = {0, 0, 0},
+                                                            std::array<double, 3> hi = {1, 1, 1},
+                                                            std::array<bool, 3> periodic = {false, false, false})
+{
+  auto part = std::make_unique<BoxPartition>();
+  BoxPartition& P = *part;
+  P.procs = decompose3d(nproc);
+  P.coords = rank_coords(rank, P.procs);
+  P.rank = rank;
+  P.degree = degree;
+  P.n_local = n;
+  P.periodic = periodic;
+  std::array<double, 3> llo, lhi;
+  P.size_global = 1;
+  for (int a = 0; a < 3; ++a) {
+    const int gn = P.procs[a] * n[a];
+    const double h = (hi[a] - lo[a]) / gn;
+    llo[a] = lo[a] + h * n[a] * P.coords[a];
+    lhi[a] = lo[a] + h * n[a] * (P.coords[a] + 1);
+    P.owned_lo[a] = (P.coords[a] > 0 || periodic[a]) ? 1 : 0;
+    P.size_global *= (std::int64_t)degree * gn + (periodic[a] ? 0 : 1);
+  }
+  P.mesh = create_box(n, llo, lhi);
+  P.V = create_functionspace(P.mesh, degree, /*build_dofmap=*/false);
+  const int NX = P.V.lattice[0], NY = P.V.lattice[1], NZ = P.V.lattice[2];
+  const int hi_idx[3] = {NX - 1, NY - 1, NZ - 1};
+  // kind -1: lower plane, +1: upper plane, 0: the owned range of that axis
+  auto lattice_indices = [&](const int kinds[3]) {
+    int b[3], e[3];
+    for (int a = 0; a < 3; ++a) {
+      b[a] = kinds[a] < 0 ? 0 : kinds[a] > 0 ? hi_idx[a] : P.owned_lo[a];
+      e[a] = kinds[a] < 0 ? 0 : hi_idx[a];
+    }
+    std::vector<std::int32_t> out;
+    for (int K = b[2]; K <= e[2]; ++K)
+      for (int J = b[1]; J <= e[1]; ++J)
+        for (int I = b[0]; I <= e[0]; ++I) out.push_back((std::int32_t)(I + NX * (J + NY * K)));
+    return out;
+  };
+  std::map<int, std::vector<std::int32_t>> send, recv;   // keyed by neighbour rank (ascending)
+  for (int dx = 0; dx < 2; ++dx)
+    for (int dy = 0; dy < 2; ++dy)
+      for (int dz = 0; dz < 2; ++dz) {
+        if (!dx && !dy && !dz) continue;
+        const int d[3] = {dx, dy, dz}, md[3] = {-dx, -dy, -dz};
+        std::array<int, 3> up, dn;
+        bool up_ok = true, dn_ok = true;
+        for (int a = 0; a < 3; ++a) {
+          up[a] = P.coords[a] + d[a];
+          dn[a] = P.coords[a] - d[a];
+          if (periodic[a]) {
+            up[a] = (up[a] + P.procs[a]) % P.procs[a];
+            dn[a] = (dn[a] + P.procs[a]) % P.procs[a];
+          }
+          up_ok = up_ok && up[a] >= 0 && up[a] < P.procs[a];
+          dn_ok = dn_ok && dn[a] >= 0 && dn[a] < P.procs[a];
+        }
+        // several directions can lead to the same neighbour (periodic): segments are
+        // concatenated in direction order, identical on the sending and receiving side
+        if (up_ok) {
+          auto v = lattice_indices(d);
+          auto& s = send[coords_rank(up, P.procs)];
+          s.insert(s.end(), v.begin(), v.end());
+        }
+        if (dn_ok) {
+          auto v = lattice_indices(md);
+          auto& r = recv[coords_rank(dn, P.procs)];
+          r.insert(r.end(), v.begin(), v.end());
+        }
+      }
+  GhostLists& g = P.ghosts;
+  g.ndofs = P.V.ndofs();
+  for (auto& kv : send) {
+    g.send_neighbors.push_back(kv.first);
+    g.send_indices.insert(g.send_indices.end(), kv.second.begin(), kv.second.end());
+    g.send_offsets.push_back((std::int32_t)g.send_indices.size());
+  }
+  for (auto& kv : recv) {
+    g.recv_neighbors.push_back(kv.first);
+    g.ghost_positions.insert(g.ghost_positions.end(), kv.second.begin(), kv.second.end());
+    g.recv_offsets.push_back((std::int32_t)g.ghost_positions.size());
+  }
+  return part;
 }
 
 /// demo/cpu_planar3d/main.cpp:48-66: h = smallest cell diameter, dt = CFL*h/(c0*P^2)

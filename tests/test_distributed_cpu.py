@@ -76,6 +76,45 @@ def test_periodic_partition_lists():
         assert np.array_equal(np.sort(allg), np.arange(parts[0].size_global))      # every global dof owned exactly once
 
 
+def test_cxx_partition_matches_python(tmp_path):
+    """include/wavehip_box.hpp create_distributed_box (the C++ host side of
+    VectorUpdater) names the same neighbours and the same dofs in the same order as
+    wave_fenics_amd.distributed, for plain and periodic partitions."""
+    import subprocess
+    from wave_fenics_amd import build
+    from wave_fenics_amd.distributed import boundary_tags, create_distributed_box
+    build.build()
+    exe = str(tmp_path / "partition_dump")
+    libdir = os.path.join(ROOT, "wave_fenics_amd")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cxx", "partition_dump.cpp"), "-o", exe,
+                           "-L", libdir, "-lwavehip", f"-Wl,-rpath,{libdir}"])
+    cases = [(1, (2, 2, 2), 2, (1, 0, 0)), (1, (2, 1, 2), 3, (1, 1, 1)), (2, (2, 2, 1), 2, (1, 1, 0)),
+             (4, (1, 2, 2), 2, (0, 0, 0)), (8, (1, 2, 1), 2, (0, 0, 0)), (8, (1, 1, 1), 3, (1, 0, 1)),
+             (6, (2, 1, 1), 1, (0, 1, 0))]
+    for world, n, p, per in cases:
+        for rank in range(world):
+            part = create_distributed_box(n, p, world, rank, periodic=per)
+            out = subprocess.run([exe] + [str(v) for v in (*n, p, world, rank, *per)], capture_output=True, text=True,
+                                 timeout=60)
+            assert out.returncode == 0, out.stderr
+            lines = out.stdout.strip().splitlines()
+            head = lines[0].split()
+            assert tuple(int(v) for v in head[1:4]) == tuple(part.procs)
+            assert tuple(int(v) for v in head[5:8]) == tuple(part.coords)
+            assert tuple(int(v) for v in head[9:12]) == tuple(part.owned_lo)
+            assert int(head[13]) == part.size_global and int(head[15]) == part.num_owned
+            send = {int(l.split()[1]): np.array(l.split()[2:], dtype=np.int32) for l in lines if l.startswith("send")}
+            recv = {int(l.split()[1]): np.array(l.split()[2:], dtype=np.int32) for l in lines if l.startswith("recv")}
+            assert sorted(send) == sorted(part.send_fwd) and sorted(recv) == sorted(part.recv_fwd)
+            for nb in send:
+                assert np.array_equal(send[nb], part.send_fwd[nb])
+            for nb in recv:
+                assert np.array_equal(recv[nb], part.recv_fwd[nb])
+            tags = {int(t.split(":")[0]): int(t.split(":")[1]) for t in lines[-1].split()[1:]}
+            assert tags == boundary_tags(part)
+
+
 def _worker(rank, world, port, n, p, perturb, q):
     try:
         import torch

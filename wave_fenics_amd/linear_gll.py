@@ -269,8 +269,7 @@ def _rk4_fused(self, startTime: float, finalTime: float, timeStep: float, max_st
                 x_u, x_v = un, vn_next
                 vn_next = vn_b if vn_next is vn_a else vn_a
             else:
-                la.rk4_stage(b, m, x_v, ur, vr, u_, v_, dt * b_runge[i])
-                la.fill(b, 0.0)
+                la.rk4_stage(b, m, x_v, ur, vr, u_, v_, dt * b_runge[i])      # also zeroes b
         u0, u_ = u_, u0          # the new solution becomes the next step's u0
         v0, v_ = v_, v0
         t += dt
