@@ -31,7 +31,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
-def cpu_baseline(sample_n: int, p: int, reps: int = 2):
+def cpu_baseline(sample_n: int, p: int, reps: int = 5):
     """The reference CPU operator (dense skernel, common/operators.hpp:113-133,
     183-200) restated in oracle/wave_oracle.c, built with the reference's flags,
     one thread per host core over a static cell partition with private y
@@ -62,8 +62,7 @@ def cpu_baseline(sample_n: int, p: int, reps: int = 2):
                 y[:] = 0.0
             t0 = time.perf_counter()
             list(ex.map(work, range(nthreads)))
-            y = np.sum(ys, axis=0)
-            times.append(time.perf_counter() - t0)
+            times.append(time.perf_counter() - t0)     # the applies only; the reduction of the private y's is not timed
     t = float(np.median(times[1:]))
     return {
         "value": om.ndofs / t, "unit": "dofs/s", "cores": nthreads, "kind": "port",
@@ -82,6 +81,9 @@ def main():
     ap.add_argument("--generic", action="store_true", help="use the arbitrary-dofmap kernel instead of the box kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=24)
+    ap.add_argument("--periodic", default="", help="axes (e.g. xyz) whose opposite faces are identified: every rank "
+                    "then has ghost planes on those axes and exchanges them over RCCL -- with one rank, with itself "
+                    "(rehearses the multi-GPU exchange + overlap path on one GPU; not the headline configuration)")
     args = ap.parse_args()
 
     import numpy as np
@@ -113,7 +115,8 @@ def main():
 
     p, n = args.degree, args.size
     updater = None
-    if world == 1:
+    periodic = tuple(c in args.periodic for c in "xyz")
+    if world == 1 and not any(periodic):
         mesh = w.create_box(n)
         V = w.create_functionspace(mesh, p, build_dofmap=args.generic)
         V.structured = not args.generic
@@ -122,14 +125,18 @@ def main():
         parallelism = "single"
     else:
         from wave_fenics_amd.distributed import create_distributed_box, VectorUpdater
-        part = create_distributed_box(n, p, world, rank)
+        part = create_distributed_box(n, p, world, rank, periodic=periodic)
         mesh, V = part.mesh, part.V
         V.structured = not args.generic
-        updater = VectorUpdater(part, device=dev)
+        # ghost exchange: the C ABI's RCCL updater (grouped ncclSend/ncclRecv per neighbour);
+        # WF_UPDATER=torch selects torch.distributed's all_to_all_single on the same index lists
+        transport = os.environ.get("WF_UPDATER", "native" if backend == "nccl" else "torch")
+        updater = VectorUpdater(part, device=dev, transport=transport)
         owned_global = part.size_global
         workload = (f"P{p} hex box, {part.procs[0]}x{part.procs[1]}x{part.procs[2]} partition, {n}^3 cells per GPU, "
                     f"{owned_global} dofs, ghost fwd + stiffness + ghost rev(add) + lumped-mass-inverse apply")
-        parallelism = f"dd{world} ({part.procs[0]}x{part.procs[1]}x{part.procs[2]})"
+        parallelism = (f"dd{world} ({part.procs[0]}x{part.procs[1]}x{part.procs[2]}), exchange={updater.transport}"
+                       + (f", periodic={args.periodic}" if any(periodic) else ""))
 
     K = w.StiffnessOperator(V, p, {"c0": 1500.0})
     M = w.MassOperatorLumped(V, p)
@@ -155,6 +162,8 @@ def main():
         # cells that read no ghost value run while the halo of x is in flight
         split = K.set_ghost_faces(*[bool(v) for v in part.owned_lo])
     from wave_fenics_amd.distributed import overlapped_apply
+    if rank == 0 and updater is not None:
+        print(f"# ghost exchange: {updater.transport}, overlap split: {split}", file=sys.stderr, flush=True)
 
     def step(ev=None):
         if split:
@@ -203,6 +212,9 @@ def main():
         alg = K.alg_bytes()
         # N > 1: the event pair brackets the whole overlapped apply (interior + interface + both halos)
         achieved = alg / (kern_ms * 1e-3) / 1e9
+        # the box kernel addresses the lattice implicitly and never reads the 4*nd dofmap
+        # bytes the contract figure includes: also report the fraction on the bytes it must move
+        must_move = alg - (4.0 * (p + 1) ** 3 * mesh.ncells if not args.generic else 0.0)
         traffic = None
         tp = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tp) and p == 4 and n == 54 and not args.generic:
@@ -223,7 +235,10 @@ def main():
                        "kernel": "generic" if args.generic else "box"},
             "roofline": {"bound": "hbm", "kernel": "stiffness apply", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": "static: profiles/traffic.json (rocprofv3 --pmc passes, not this run)" if traffic else None,
                          "alg_bytes_per_launch": alg, "kernel_ms": kern_ms,
+                         "must_move_bytes_per_launch": must_move,
+                         "frac_must_move": must_move / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "stiffness_only_dofs_per_s": V.ndofs / (kern_ms * 1e-3)},
         }
         if not args.no_cpu_baseline and world == 1:

@@ -5,8 +5,7 @@ through device buffers -- the code path the multi-GPU run uses, with the same
 index lists.  The answer is the CPU oracle on the periodic mesh
 (oracle.make_periodic).  Replaces demo/gpu_scatter_mpi/VectorUpdater.hpp:106-208.
 
-Tolerances: index work bit-exact; one apply 1e-12 (handed-over / generic) and
-1e-11 (device-computed box geometry); 20 RK4 steps 1e-9."""
+Tolerances: index work bit-exact; one apply 1e-12; 20 RK4 steps 1e-9."""
 import numpy as np
 import pytest
 
@@ -125,7 +124,7 @@ def test_periodic_stiffness_vs_oracle(gpu, comm, oracle, p, n, periodic, perturb
             vu.update_rev(y)
         torch.cuda.synchronize()
         err = relerr(y.cpu().numpy()[owned], yg[l2g[owned]])
-        assert err <= (1e-12 if mode == "generic" else 1e-11), (mode, err)
+        assert err <= 1e-12, (mode, err)
 
 
 def test_periodic_rk4_vs_oracle(gpu, comm, oracle):
