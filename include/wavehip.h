@@ -93,7 +93,11 @@ typedef enum {
 typedef enum {
   WF_FLAG_NONE = 0,
   WF_FLAG_NO_FABS = 1,     /* detJ keeps its sign (spectral_mass.hpp:58-64)    */
-  WF_FLAG_NO_CLAMP = 2     /* skip the -1/0/1 clamp of G                        */
+  WF_FLAG_NO_CLAMP = 2,    /* skip the -1/0/1 clamp of G                        */
+  WF_FLAG_MASS_ELEMENTWISE = 4 /* lumped mass with a dofmap: apply as the reference's
+                              gather * detJ -> scatter-add per cell
+                              (spectral_mass.hpp:84-89) instead of the pre-assembled
+                              diagonal y += m .* x (m = M 1 built once at create)  */
 } wf_flags;
 
 typedef struct {
@@ -297,6 +301,30 @@ int wf_updater_destroy(wf_updater* u);
  * runs update_fwd(x) -> apply(INTERFACE) -> update_rev(y) beside apply(INTERIOR) on
  * `stream`, which continues after both.  Needs wf_op_set_ghost_faces. */
 int wf_op_apply_overlapped(wf_op* op, wf_updater* u, double* d_x, double* d_y, void* stream);
+
+/* ---- 8f: matrix-free conjugate gradients (BP1) -----------------------------
+ * device::cg(x, b, matvec, kmax, rtol) of demo/gpu_cg/CUDA/cg.hpp:38-121: solves
+ * A x = b for a symmetric positive definite operator, x holding the initial guess;
+ * stops when ||r||^2 / ||r0||^2 < rtol^2 (cg.hpp:103) or after kmax iterations.
+ * A is an operator handle or a callback with the library's accumulate semantics
+ * (y += A v; wf_cg zeroes y first).  On a partitioned mesh pass the updater and
+ * its communicator: the halo of the direction is updated before, the product
+ * accumulated to the owners after every matvec, and the reductions run over owned
+ * entries with one scalar all-reduce each (the MPI_Allreduce of cg.hpp:15-24).
+ * The textbook algorithm is implemented, not the reference loop's arithmetic
+ * (update_rev(p), nrm2 used as a squared norm, axpy(1,p,r): cg.hpp:84,59,117). */
+typedef int (*wf_matvec_fn)(void* user, const double* d_v, double* d_y, void* stream);
+typedef struct {
+  int64_t n;              /* local vector length (owned + ghost)                  */
+  wf_op* op;              /* A; used when matvec is NULL                           */
+  wf_matvec_fn matvec;    /* or a callback, y += A v                               */
+  void* user;
+  wf_updater* updater;    /* NULL on one rank                                       */
+  wf_comm* comm;          /* NULL on one rank                                       */
+  int kmax;               /* reference default 50                                   */
+  double rtol;            /* reference default 1e-8                                 */
+} wf_cg_desc;
+int wf_cg(const wf_cg_desc* desc, double* d_x, const double* d_b, int* iterations, double* rel_residual, void* stream);
 
 #ifdef __cplusplus
 }

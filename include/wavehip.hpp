@@ -15,6 +15,7 @@
 
 #include <cstdint>
 #include <cstdlib>
+#include <functional>
 #include <map>
 #include <memory>
 #include <stdexcept>
@@ -336,22 +337,70 @@ public:
   void update_rev_end(T* x, void* stream = nullptr) { check(wf_updater_rev_end(_u, x, stream)); }
   void update_rev(T* x, void* stream = nullptr) { check(wf_updater_rev(_u, x, stream)); }
   template <typename Vector>
-  void update_fwd_begin(const Vector& x) { update_fwd_begin(x.array().data()); }
+  void update_fwd_begin(const Vector& x) { update_fwd_begin(static_cast<const T*>(x.array().data())); }
   template <typename Vector>
-  void update_fwd_end(Vector& x) { update_fwd_end(x.mutable_array().data()); }
+  void update_fwd_end(Vector& x) { update_fwd_end(static_cast<T*>(x.mutable_array().data())); }
   template <typename Vector>
-  void update_fwd(Vector& x) { update_fwd(x.mutable_array().data()); }
+  void update_fwd(Vector& x) { update_fwd(static_cast<T*>(x.mutable_array().data())); }
   template <typename Vector>
-  void update_rev_begin(const Vector& x) { update_rev_begin(x.array().data()); }
+  void update_rev_begin(const Vector& x) { update_rev_begin(static_cast<const T*>(x.array().data())); }
   template <typename Vector>
-  void update_rev_end(Vector& x) { update_rev_end(x.mutable_array().data()); }
+  void update_rev_end(Vector& x) { update_rev_end(static_cast<T*>(x.mutable_array().data())); }
   template <typename Vector>
-  void update_rev(Vector& x) { update_rev(x.mutable_array().data()); }
+  void update_rev(Vector& x) { update_rev(static_cast<T*>(x.mutable_array().data())); }
   wf_updater* handle() const { return _u; }
 
 private:
   wf_updater* _u = nullptr;
 };
+
+// ---- device::cg (demo/gpu_cg/CUDA/cg.hpp:38-121) -------------------------------
+namespace device {
+/// Solve A x = b with the conjugate gradient method; returns the iteration count.
+/// matvec(p, y) must ACCUMULATE y += A p on raw device pointers (cg zeroes y first),
+/// e.g. [&](const double* p, double* y, void* s) { op.apply(p, y, s); }.  x holds the
+/// initial guess.  On a partitioned mesh pass the VectorUpdater and its Comm.
+/// Textbook CG with the reference's stopping rule (cg.hpp:103); see wf_cg.
+template <typename T>
+int cg(T* x, const T* b, std::int64_t n, std::function<void(const T*, T*, void*)> matvec, int kmax = 50,
+       double rtol = 1e-8, VectorUpdater<T>* updater = nullptr, Comm* comm = nullptr, double* rel_residual = nullptr)
+{
+  static_assert(sizeof(T) == sizeof(double), "fp64 only");
+  struct Ctx {
+    std::function<void(const T*, T*, void*)>* f;
+    std::string what;
+  } ctx{&matvec, {}};
+  wf_cg_desc d{};
+  d.n = n;
+  d.user = &ctx;
+  d.matvec = [](void* user, const double* v, double* y, void* stream) -> int {
+    auto* c = static_cast<Ctx*>(user);
+    try {
+      (*c->f)(v, y, stream);
+      return 0;
+    } catch (const std::exception& e) {   // exceptions must not cross the C boundary
+      c->what = e.what();
+      return -1;
+    }
+  };
+  d.updater = updater ? updater->handle() : nullptr;
+  d.comm = comm ? comm->handle() : nullptr;
+  d.kmax = kmax;
+  d.rtol = rtol;
+  int its = 0;
+  const int rc = wf_cg(&d, x, b, &its, rel_residual, nullptr);
+  if (rc != WF_OK && !ctx.what.empty()) throw std::runtime_error("wavehip::device::cg: matvec threw: " + ctx.what);
+  check(rc);
+  return its;
+}
+/// Vector-concept overload with the reference's argument order.
+template <typename Vector>
+int cg(Vector& x, const Vector& b, std::function<void(const double*, double*, void*)> matvec, int kmax = 50,
+       double rtol = 1e-8)
+{
+  return cg<double>(x.mutable_array().data(), b.array().data(), (std::int64_t)x.array().size(), std::move(matvec), kmax, rtol);
+}
+}  // namespace device
 
 // ---- linalg:: (common/cuda/la.hpp:31-138) and kernels:: (LinearGLL.hpp:15-35)
 namespace linalg {

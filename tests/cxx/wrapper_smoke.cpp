@@ -61,6 +61,15 @@ int main(int argc, char**)
     std::vector<double> h(16);
     a.set(h);
     auto b = a.copy_to_host();
+    // ghost exchange + CG wrappers (VectorUpdater.hpp, gpu_cg/CUDA/cg.hpp)
+    wavehip::GhostLists gl;
+    wavehip::VectorUpdater<double> vu(nullptr, gl);
+    vu.update_fwd(x);
+    vu.update_rev(x);
+    vu.update_fwd_begin(x);
+    vu.update_fwd_end(x);
+    int its = wavehip::device::cg(x, y, [&](const double* p, double* q, void* s) { M.apply(p, q, s); }, 50, 1e-8);
+    (void)its;
     wavehip::gather<double>(0, nullptr, nullptr, nullptr, 512);
     wavehip::scatter<double>(0, nullptr, nullptr, nullptr, 512);
     wavehip::transform1<double>(0, nullptr, nullptr, nullptr, 512);

@@ -223,11 +223,15 @@ def test_lumped_mass_vs_oracle(gpu, oracle, p, n):
         y = dev(y0, gpu)
         op(dev(x, gpu), y)
         assert relerr(y.cpu().numpy(), yref) <= 1e-13
-    # handed-over detJ (reference layout)
-    op = w.MassOperatorLumped(V, p, detJ=M.detJ, structured=False)
-    y = dev(y0, gpu)
-    op.apply(dev(x, gpu), y)
-    assert relerr(y.cpu().numpy(), yref) <= 1e-14
+    # handed-over detJ (reference layout): pre-assembled diagonal (default) and the
+    # reference's element-wise gather * detJ -> scatter-add order (spectral_mass.hpp:84-89)
+    from wave_fenics_amd import _lib
+    for flags in (0, _lib.WF_FLAG_MASS_ELEMENTWISE):
+        op = w.MassOperatorLumped(V, p, detJ=M.detJ, structured=False, flags=flags)
+        y = dev(y0, gpu)
+        op.apply(dev(x, gpu), y)
+        assert relerr(y.cpu().numpy(), yref) <= 1e-14
+        assert op.alg_bytes() == (24.0 * om.ndofs if flags == 0 else om.ncells * (8.0 + 4.0) * (p + 1) ** 3 + 16.0 * om.ndofs)
 
 
 def test_spectral_mass_x_ones(gpu, oracle):

@@ -54,11 +54,21 @@ class UpdaterDesc(ctypes.Structure):
     ]
 
 
+MATVEC_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_void_p, c_void_p)
+
+
+class CGDesc(ctypes.Structure):
+    _fields_ = [
+        ("n", c_int64), ("op", c_void_p), ("matvec", MATVEC_FN), ("user", c_void_p),
+        ("updater", c_void_p), ("comm", c_void_p), ("kmax", c_int), ("rtol", c_double),
+    ]
+
+
 WF_COMM_ID_BYTES = 128
 WF_SUM, WF_MAX = 0, 1
 WF_UPDATER_DEFAULT, WF_UPDATER_INLINE = 0, 1
 WF_OP_STIFFNESS, WF_OP_MASS_LUMPED, WF_OP_MASS_DENSE = 0, 1, 2
-WF_FLAG_NONE, WF_FLAG_NO_FABS, WF_FLAG_NO_CLAMP = 0, 1, 2
+WF_FLAG_NONE, WF_FLAG_NO_FABS, WF_FLAG_NO_CLAMP, WF_FLAG_MASS_ELEMENTWISE = 0, 1, 2, 4
 WF_PART_ALL, WF_PART_INTERIOR, WF_PART_INTERFACE, WF_PART_INTERIOR_A, WF_PART_INTERIOR_B = 0, 1, 2, 3, 4
 
 # every symbol include/wavehip.h declares: name -> (restype, argtypes)
@@ -117,6 +127,7 @@ SIGNATURES = {
     "wf_updater_info": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
     "wf_updater_destroy": (c_int, [c_void_p]),
     "wf_op_apply_overlapped": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "wf_cg": (c_int, [POINTER(CGDesc), c_void_p, c_void_p, POINTER(c_int), POINTER(c_double), c_void_p]),
     "wf_boundary_apply": (c_int, [c_int32, c_void_p, c_void_p, c_double, c_int32, c_void_p, c_void_p, c_double,
                                   c_void_p, c_void_p, c_void_p]),
 }

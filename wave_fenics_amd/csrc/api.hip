@@ -432,7 +432,10 @@ int wf_op_create(const wf_op_desc* desc, wf_op** out)
       const int CBm = (desc->kind == WF_OP_MASS_DENSE && !square) ? mass_dense_cells_per_batch(mx) : cells_per_batch(P);
       // dense mass: the unique-dof tile pays off only for small elements (measured at 10 M dofs:
       // P2 0.80 -> 0.68 ms, P4 0.43 -> 0.46 ms, P6 0.34 -> 0.41 ms)
-      const bool want = desc->kind == WF_OP_MASS_LUMPED || P <= 3 || square;
+      // lumped mass: the diagonal is pre-assembled below unless the caller asks for the
+      // reference's element-wise sequence
+      const bool elementwise = desc->kind == WF_OP_MASS_LUMPED && (desc->flags & WF_FLAG_MASS_ELEMENTWISE);
+      const bool want = elementwise || (desc->kind == WF_OP_MASS_DENSE && (P <= 3 || square));
       if (want && !(gk && std::strcmp(gk, "flat") == 0) && (rc = build_unique_lists(op.get(), ncells, nd, CBm)) != WF_OK)
         return rc;
     }
@@ -446,6 +449,24 @@ int wf_op_create(const wf_op_desc* desc, wf_op** out)
     } else if (ncells) {
       set_error("wf_op_create: mass needs h_detJ or the mesh (h_xverts, h_geom_dofmap)");
       return WF_ERR_INVALID;
+    }
+    if (desc->kind == WF_OP_MASS_LUMPED && !(desc->flags & WF_FLAG_MASS_ELEMENTWISE)) {
+      // A lumped mass is a diagonal: assemble m = M 1 once with the reference's own
+      // sequence (gather 1, * detJ, scatter-add; spectral_mass.hpp:84-89) and apply it as
+      // y += m .* x -- 24 B/dof instead of 8 nq + 4 nd per cell + 16 per dof.
+      Scratch<double> d_ones;
+      if ((rc = dev_alloc(&d_ones.p, (size_t)op->ndofs, nullptr)) != WF_OK) return rc;
+      if ((rc = dev_alloc(&op->d_mdiag, (size_t)op->ndofs, &op->device_bytes)) != WF_OK) return rc;
+      if (op->ndofs) {
+        if ((rc = wf_fill(op->ndofs, 1.0, d_ones.p, nullptr)) != WF_OK) return rc;
+        WF_HIP_CHECK(hipMemset(op->d_mdiag, 0, (size_t)op->ndofs * sizeof(double)));
+        if (ncells && (rc = launch_mass_lumped((int64_t)ncells * nd, op->d_dofmap, op->d_detJ, d_ones.p, op->d_mdiag, nullptr)) != WF_OK)
+          return rc;
+        WF_HIP_CHECK(hipDeviceSynchronize());
+      }
+      op->device_bytes -= ncells * nd * sizeof(double);
+      (void)hipFree(op->d_detJ);
+      op->d_detJ = nullptr;
     }
   }
   WF_HIP_CHECK(hipDeviceSynchronize());
@@ -638,6 +659,7 @@ int wf_op_apply(wf_op* op, const double* d_x, double* d_y, void* stream)
       return launch_stiffness_generic(op->P, op->ncells, op->d_dofmap, op->d_G6blk, op->d_D, op->dm, op->coeff, d_x,
                                       d_y, s);
     case WF_OP_MASS_LUMPED:
+      if (op->d_mdiag) return wf_pointwise_mult_add(op->ndofs, op->d_mdiag, d_x, d_y, stream);
       if (op->generic_unique)
         return launch_mass_lumped_u(op->ncells, op->nd, op->unique_cb, op->d_uoff, op->d_uniq, op->d_loc, op->d_detJ, d_x,
                                     d_y, s);
@@ -717,8 +739,8 @@ int wf_op_info(const wf_op* op, wf_op_info_t* info)
     info->alg_bytes = (double)op->ncells * (48.0 + 4.0 * op->nd) + 16.0 * op->ndofs;
   } else if (op->kind == WF_OP_STIFFNESS)
     info->alg_bytes = (double)op->ncells * (48.0 * op->nq + 4.0 * op->nd) + 16.0 * op->ndofs;
-  else if (op->structured)
-    info->alg_bytes = 24.0 * op->ndofs;
+  else if (op->d_mdiag)
+    info->alg_bytes = 24.0 * op->ndofs;   // pre-assembled diagonal: read m, x, y + write y (SURVEY 8d counts 24)
   else
     info->alg_bytes = (double)op->ncells * (8.0 * op->nq + 4.0 * op->nd) + 16.0 * op->ndofs;
   info->device_bytes = op->device_bytes;

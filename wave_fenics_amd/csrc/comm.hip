@@ -438,6 +438,15 @@ int wf_updater_info(const wf_updater* u, int* num_send, int* num_recv, int* num_
   return WF_OK;
 }
 
+// internal (cg.hip): the ghost positions, for reductions over owned entries only
+int wf_updater_ghosts(const wf_updater* u, const int32_t** d_ghost_pos, int32_t* nghost)
+{
+  WF_REQUIRE(u && d_ghost_pos && nghost, "wf_updater_ghosts: null argument");
+  *d_ghost_pos = u->d_ghost_pos;
+  *nghost = u->nrecv;
+  return WF_OK;
+}
+
 int wf_updater_destroy(wf_updater* u)
 {
   free_updater(u);

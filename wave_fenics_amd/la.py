@@ -67,3 +67,62 @@ def rk4_stage(b, m, vn, u_read, v_read, u, v, bdt: float, adt_next: float = 0.0,
                              _ptr(u_read), _ptr(v_read), _ptr(u), _ptr(v),
                              _ptr(u0) if has_next else z, _ptr(v0) if has_next else z,
                              _ptr(un) if has_next else z, _ptr(vn_next) if has_next else z, _stream(b)))
+
+
+def cg(x, b, A, kmax: int = 50, rtol: float = 1e-8, updater=None, comm=None):
+    """device::cg(x, b, matvec, kmax, rtol) of demo/gpu_cg/CUDA/cg.hpp:38-121 (wf_cg):
+    solves A x = b, x holding the initial guess.  A is an operator of this package or a
+    callable matvec(v, y) with accumulate semantics (y += A v) on device tensors.
+    Returns (iterations, relative residual ||r|| / ||r0||)."""
+    import ctypes
+
+    import torch
+
+    from . import _lib
+    d = _lib.CGDesc()
+    d.n = x.numel()
+    keep = None
+    if hasattr(A, "_h"):
+        d.op = A._h
+    else:
+        dev, n = x.device, x.numel()
+
+        def tramp(user, pv, py, stream):
+            try:
+                # wrap the raw pointers as tensors (no copy) and run the callable on wf_cg's stream
+                v = _tensor_from_ptr(pv, n, dev)
+                y = _tensor_from_ptr(py, n, dev)
+                # torch.cuda.ExternalStream(0) is NOT the null stream on ROCm (it wraps a bogus handle)
+                st = torch.cuda.ExternalStream(stream, device=dev) if stream else torch.cuda.default_stream(dev)
+                with torch.cuda.stream(st):
+                    A(v, y)
+                return 0
+            except Exception:   # exceptions must not cross the C boundary
+                import traceback
+                traceback.print_exc()
+                return -1
+        keep = _lib.MATVEC_FN(tramp)
+        d.matvec = keep
+    if updater is not None:
+        if getattr(updater, "transport", None) != "native":
+            raise _lib.WavehipError("cg on a partitioned mesh needs the native (RCCL) VectorUpdater")
+        d.updater = updater._h
+        comm = comm if comm is not None else updater.comm
+    if comm is not None:
+        d.comm = comm._h
+    d.kmax, d.rtol = int(kmax), float(rtol)
+    its, res = ctypes.c_int(0), ctypes.c_double(0.0)
+    check(lib().wf_cg(ctypes.byref(d), _ptr(x), _ptr(b), ctypes.byref(its), ctypes.byref(res), _stream(x)))
+    return int(its.value), float(res.value)
+
+
+def _tensor_from_ptr(ptr: int, n: int, device):
+    """A float64 tensor view of device memory owned by libwavehip (plumbing for callbacks)."""
+    import torch
+
+    class _Holder:
+        pass
+
+    h = _Holder()
+    h.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
+    return torch.as_tensor(h, device=device)
