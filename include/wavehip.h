@@ -64,6 +64,21 @@ int wf_sync(void* stream);                           /* cudaDeviceSynchronize  *
  * Any output pointer may be NULL. */
 int wf_tabulate_gll(int P, double* h_points, double* h_weights, double* h_D);
 
+/* 1-D quadrature rules as basix::quadrature::make_quadrature(type, interval, degree)
+ * selects them (common/precompute.hpp:183-184, demo/gpu_operator/main.cpp:96-99,
+ * common/operators.hpp:19): Gauss-Jacobi (alpha = beta = 0, i.e. Gauss-Legendre) with
+ * (degree+2)/2 points, GLL with (degree+4)/2 points; on [0,1], ascending.
+ * *npts is always set; h_points / h_weights (capacity WF_MAX_QUAD_POINTS) may be NULL. */
+typedef enum { WF_QUAD_GLL = 0, WF_QUAD_GAUSS_JACOBI = 1 } wf_quadrature_type;
+typedef enum { WF_VARIANT_GLL_WARPED = 0, WF_VARIANT_EQUISPACED = 1 } wf_lagrange_variant;
+#define WF_MAX_QUAD_POINTS 16
+int wf_quadrature_1d(int type, int degree, int* npts, double* h_points, double* h_weights);
+
+/* common/precompute.hpp:179-189 tabulate_1d: the degree-P Lagrange basis of the given
+ * variant on the interval at npts points; h_table[q*(P+1) + a] = l_a(x_q) (derivative 0)
+ * or l_a'(x_q) (derivative 1).  Not clamped (neither is the reference's). */
+int wf_tabulate_1d(int P, int variant, int npts, const double* h_points, int derivative, double* h_table);
+
 /* Dense reference-layout table[4][nq][nd] (0 = values, 1..3 = d/dx,d/dy,d/dz),
  * nq = nd = (P+1)^3, tensor ordering, clamped (operators.hpp:23-29). */
 int wf_tabulate_dense(int P, double* h_table);
@@ -81,6 +96,15 @@ int wf_reorder_dofmap(int ncells, int nd, const int32_t* h_perm,
 int wf_geometry_hex(int P, int ncells, int nverts, const double* h_xverts,
                     const int32_t* h_geom_dofmap, int use_fabs, int clamp,
                     double* h_G, double* h_detJ);
+
+/* The generic helpers of common/precompute.hpp:49-176 (compute_jacobian, _determinant,
+ * _inverse, compute_geometrical_factor) at an arbitrary tensor-product rule
+ * nq1 x nq1 x nq1 (point q = i + nq1*(j + nq1*k), weight w_i w_j w_k):
+ * h_detJ [ncells][nq1^3] = det J * w (|det J| * w with use_fabs), h_G [ncells][nq1^3][3][3]
+ * = K K^T detJ w.  Either output may be NULL. */
+int wf_geometry_hex_rule(int ncells, int nverts, const double* h_xverts, const int32_t* h_geom_dofmap, int nq1,
+                         const double* h_points1, const double* h_weights1, int use_fabs, int clamp, double* h_G,
+                         double* h_detJ);
 
 /* ---- operators -----------------------------------------------------------*/
 typedef enum {
@@ -122,6 +146,10 @@ typedef struct {
    * of a tensor-product rule; h_detJ is then [ncells][nq1^3].                   */
   int nq1;
   const double* h_phi1;
+  /* WF_OP_MASS_DENSE with the mesh instead of h_detJ: the 1-D rule (points, weights
+   * [nq1]) at which det J * w is computed on the device (mass.hpp:35-39).        */
+  const double* h_qpts1;
+  const double* h_qwts1;
 } wf_op_desc;
 
 /* Op(V, degree[, params]) constructors: operators.hpp:53,149; mass.hpp:20;

@@ -224,6 +224,24 @@ public:
     d.h_detJ = detJ;
     check(wf_op_create(&d, &_op));
   }
+  /// The reference's argument list (mass.hpp:20-21): element = degree + Lagrange variant
+  /// (WF_VARIANT_GLL_WARPED / WF_VARIANT_EQUISPACED), quad_type (WF_QUAD_GLL /
+  /// WF_QUAD_GAUSS_JACOBI) and quadrature degree qd.  Builds the 1-D table (tabulate_1d,
+  /// precompute.hpp:179-189) on the host and det J * w at the rule's points on the device.
+  MassOperator(const Space& V, int degree, int variant, int quad_type, int qd)
+  {
+    int nq1 = 0;
+    double pts[WF_MAX_QUAD_POINTS], wts[WF_MAX_QUAD_POINTS];
+    check(wf_quadrature_1d(quad_type, qd, &nq1, pts, wts));
+    std::vector<double> phi1((std::size_t)nq1 * (degree + 1));
+    check(wf_tabulate_1d(degree, variant, nq1, pts, 0, phi1.data()));
+    wf_op_desc d = base_desc(V, WF_OP_MASS_DENSE, degree);
+    d.nq1 = nq1;
+    d.h_phi1 = phi1.data();
+    d.h_qpts1 = pts;
+    d.h_qwts1 = wts;
+    check(wf_op_create(&d, &_op));
+  }
 };
 
 /// Structured box operators (mesh::create_box with this engine's numbering).

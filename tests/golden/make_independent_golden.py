@@ -54,6 +54,32 @@ def gll_rule(n):
     return [(x + 1) / 2 for x in nodes], [v / 2 for v in w]
 
 
+def gauss_rule(m):
+    """m-point Gauss-Legendre rule on [0,1]: nodes = roots of P_m, w = 2 / ((1-x^2) P_m'(x)^2)."""
+    P = sp.legendre(m, X)
+    nodes = sorted(mp.mpf(sp.N(r, 45)) for r in sp.real_roots(sp.Poly(P, X)))
+    dP = sp.lambdify(X, sp.diff(P, X), "mpmath")
+    w = [2 / ((1 - x * x) * dP(x) ** 2) for x in nodes]
+    return [(x + 1) / 2 for x in nodes], [v / 2 for v in w]
+
+
+def lagrange_table(nodes, pts, derivative):
+    """table[q][a] = l_a(pts[q]) (or its derivative), symbolic Lagrange polynomials through `nodes`."""
+    n = len(nodes)
+    sn = [sp.Float(str(v), 45) for v in nodes]
+    T = [[None] * n for _ in pts]
+    for a in range(n):
+        la = sp.Integer(1)
+        for b in range(n):
+            if b != a:
+                la = la * (X - sn[b]) / (sn[a] - sn[b])
+        e = sp.expand(la)
+        f = sp.lambdify(X, sp.diff(e, X) if derivative else e, "mpmath")
+        for q, x in enumerate(pts):
+            T[q][a] = f(x)
+    return T
+
+
 def lagrange_derivative_matrix(nodes):
     """D[q][a] = l_a'(nodes[q]) by symbolic differentiation of the Lagrange polynomials."""
     n = len(nodes)
@@ -193,6 +219,21 @@ def main():
         D = lagrange_derivative_matrix(nodes)
         out["gll"][str(n - 1)] = {"points": enc(to_f(nodes)), "weights": enc(to_f(wts)), "D": enc(to_f(D))}
         print("gll", n, flush=True)
+    # Gauss-Legendre rules (basix gauss_jacobi on the interval, precompute.hpp:183-184) and the
+    # tables of tabulate_1d (precompute.hpp:179-189) / demo/gpu_operator (equispaced basis, degree 2P rule)
+    out["gauss"] = {}
+    for m in range(1, 9):
+        nodes, wts = gauss_rule(m)
+        out["gauss"][str(m)] = {"points": enc(to_f(nodes)), "weights": enc(to_f(wts))}
+    out["tabulate_1d"] = []
+    for p in (2, 3, 4, 6):
+        gpts, _ = gauss_rule(p + 1)               # degree 2P -> (2P+2)/2 = P+1 points
+        for variant in ("gll_warped", "equispaced"):
+            nodes = gll_rule(p + 1)[0] if variant == "gll_warped" else [mp.mpf(a) / p for a in range(p + 1)]
+            out["tabulate_1d"].append({"p": p, "variant": variant, "points": enc(to_f(gpts)),
+                                       "phi": enc(to_f(lagrange_table(nodes, gpts, 0))),
+                                       "dphi": enc(to_f(lagrange_table(nodes, gpts, 1)))})
+        print("tabulate_1d", p, flush=True)
     for p, n in [(1, (2, 2, 2)), (2, (2, 2, 2)), (3, (2, 1, 2)), (4, (1, 2, 1))]:
         r = operators_on_mesh(p, n, 1500.0)
         out["mesh_cases"].append({k: (enc(v) if isinstance(v, np.ndarray) else v) for k, v in r.items()})

@@ -275,6 +275,18 @@ def test_dense_mass_vs_oracle(gpu, oracle, p, variant, quad, qd):
     op.apply(dev(x, gpu), y)
     assert relerr(y.cpu().numpy(), yref) <= TOL
     assert op.flops() == 4.0 * om.ncells * phi.shape[0] * phi.shape[1]
+    # a13 in the product: the reference's argument list MassOperator(V, element, quad_type, qd)
+    # (mass.hpp:20-21) -- rule, 1-D table and det J * w at the rule's points all built by
+    # libwavehip (wf_quadrature_1d, wf_tabulate_1d, device geometry), nothing taken from oracle/
+    op2 = w.MassOperator(V, p, variant=variant, quad=quad, qdegree=qd)
+    assert np.abs(op2.points1 - pts).max() <= 3e-16 and np.abs(op2.weights1 - wts).max() <= 1e-15
+    y2 = dev(np.zeros(om.ndofs), gpu)
+    op2.apply(dev(x, gpu), y2)
+    assert relerr(y2.cpu().numpy(), yref) <= TOL
+    assert op2.num_quads() == phi.shape[0]
+    G, dj = w.compute_geometry_rule(mesh, pts, wts, want_G=True)       # precompute.hpp:49-176
+    assert relerr(dj, detJ) <= 1e-14
+    assert np.abs(G - np.swapaxes(G, 2, 3)).max() <= 1e-14 * np.abs(G).max()
 
 
 def test_gather_scatter_transform(gpu, oracle):
@@ -670,6 +682,18 @@ def test_cxx_host_driver_cfg1(gpu, oracle, tmp_path):
     vals = {l.split(":")[0].strip(): l.split(":")[1].strip() for l in r.stdout.splitlines() if ":" in l}
     assert abs(float(vals["Y norm"]) - np.linalg.norm(m)) <= 1e-5 * np.linalg.norm(m)     # printed with 6 digits
     assert int(vals["Number of cells"]) == 216 and int(vals["Number of dofs"]) == 125
+    # --op dense --check (gpu_operator_monolithic/main.cpp:93-118): the dense MassOperator built from
+    # the reference's element / quadrature arguments against the lumped operator with x = 1
+    r = subprocess.run([os.path.join(out, "operator_demo"), "--size", "5", "--degree", "3", "--op", "dense", "--check",
+                        "--reps", "2"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert "entries differing by > 1e-8: 0" in r.stdout and "Number of quads: 64" in r.stdout
+    r = subprocess.run([os.path.join(out, "operator_demo"), "--size", "4", "--degree", "2", "--op", "dense", "--check",
+                        "--variant", "equispaced", "--quad", "gauss", "--qdegree", "4", "--reps", "2"],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    line = [l for l in r.stdout.splitlines() if l.startswith("check:")][0].split()
+    assert abs(float(line[3]) - 1.0) <= 1e-12 and abs(float(line[6]) - 1.0) <= 1e-12      # both sum to the volume
 
 
 def test_generic_ops_random_cell_order(gpu, oracle):

@@ -13,5 +13,6 @@ from .box import BoxMesh, FunctionSpace, IndexMap, create_box, create_functionsp
 from .operators import (  # noqa: F401
     StiffnessOperator, MassOperator, SpectralMassOperator, MassOperatorLumped,
     gather, scatter, transform1, tsmm, tabulate_gll, tabulate_dense, precompute_geometric_data,
+    quadrature_1d, tabulate_1d, compute_geometry_rule,
 )
 from . import la  # noqa: F401

@@ -22,6 +22,7 @@ class OpDesc(ctypes.Structure):
         ("nverts", c_int), ("h_xverts", POINTER(c_double)), ("h_geom_dofmap", POINTER(c_int32)),
         ("c0", c_double), ("flags", c_int),
         ("nq1", c_int), ("h_phi1", POINTER(c_double)),
+        ("h_qpts1", POINTER(c_double)), ("h_qwts1", POINTER(c_double)),
     ]
 
 
@@ -64,6 +65,9 @@ class CGDesc(ctypes.Structure):
     ]
 
 
+WF_QUAD_GLL, WF_QUAD_GAUSS_JACOBI = 0, 1
+WF_VARIANT_GLL_WARPED, WF_VARIANT_EQUISPACED = 0, 1
+WF_MAX_QUAD_POINTS = 16
 WF_COMM_ID_BYTES = 128
 WF_SUM, WF_MAX = 0, 1
 WF_UPDATER_DEFAULT, WF_UPDATER_INLINE = 0, 1
@@ -87,6 +91,9 @@ SIGNATURES = {
     "wf_sync": (c_int, [c_void_p]),
     "wf_tabulate_gll": (c_int, [c_int, _dp, _dp, _dp]),
     "wf_tabulate_dense": (c_int, [c_int, _dp]),
+    "wf_quadrature_1d": (c_int, [c_int, c_int, POINTER(c_int), _dp, _dp]),
+    "wf_tabulate_1d": (c_int, [c_int, c_int, c_int, _dp, c_int, _dp]),
+    "wf_geometry_hex_rule": (c_int, [c_int, c_int, _dp, _ip, c_int, _dp, _dp, c_int, c_int, _dp, _dp]),
     "wf_reorder_dofmap": (c_int, [c_int, c_int, _ip, _ip, _ip]),
     "wf_geometry_hex": (c_int, [c_int, c_int, c_int, _dp, _ip, c_int, c_int, _dp, _dp]),
     "wf_op_create": (c_int, [POINTER(OpDesc), POINTER(c_void_p)]),

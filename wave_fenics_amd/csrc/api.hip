@@ -236,6 +236,39 @@ int wf_sync(void* stream)
 }
 
 // ---- geometry --------------------------------------------------------------
+static int geometry_hex_rule(int n, const double* h_pts, const double* h_wts, int ncells, int nverts,
+                             const double* h_xverts, const int32_t* h_geom_dofmap, int use_fabs, int clamp, double* h_G,
+                             double* h_detJ, const char* who)
+{
+  if (!(ncells >= 0 && nverts >= 0 && h_xverts && h_geom_dofmap)) {
+    set_error(std::string(who) + ": bad arguments");
+    return WF_ERR_INVALID;
+  }
+  for (size_t e = 0; e < (size_t)ncells * 8; ++e)
+    if (h_geom_dofmap[e] < 0 || h_geom_dofmap[e] >= nverts) {
+      set_error(std::string(who) + ": vertex index out of range");
+      return WF_ERR_INVALID;
+    }
+  const size_t nq = (size_t)n * n * n;
+  Scratch<double> d_x, d_pts, d_wts, d_G, d_det;
+  Scratch<int32_t> d_gd;
+  int rc;
+  if ((rc = dev_upload(&d_x.p, h_xverts, (size_t)nverts * 3, nullptr)) != WF_OK) return rc;
+  if ((rc = dev_upload(&d_gd.p, h_geom_dofmap, (size_t)ncells * 8, nullptr)) != WF_OK) return rc;
+  if ((rc = dev_upload(&d_pts.p, h_pts, (size_t)n, nullptr)) != WF_OK) return rc;
+  if ((rc = dev_upload(&d_wts.p, h_wts, (size_t)n, nullptr)) != WF_OK) return rc;
+  if (h_G && (rc = dev_alloc(&d_G.p, (size_t)ncells * nq * 9, nullptr)) != WF_OK) return rc;
+  if (h_detJ && (rc = dev_alloc(&d_det.p, (size_t)ncells * nq, nullptr)) != WF_OK) return rc;
+  // the kernel is generic in the number of points per direction (P + 1 = n)
+  if ((rc = launch_geometry_hex(n - 1, ncells, d_x.p, d_gd.p, d_pts.p, d_wts.p, use_fabs, clamp, d_G.p, nullptr,
+                                d_det.p, nullptr)) != WF_OK)
+    return rc;
+  WF_HIP_CHECK(hipDeviceSynchronize());
+  if (h_G) WF_HIP_CHECK(hipMemcpy(h_G, d_G.p, (size_t)ncells * nq * 9 * sizeof(double), hipMemcpyDeviceToHost));
+  if (h_detJ) WF_HIP_CHECK(hipMemcpy(h_detJ, d_det.p, (size_t)ncells * nq * sizeof(double), hipMemcpyDeviceToHost));
+  return WF_OK;
+}
+
 int wf_geometry_hex(int P, int ncells, int nverts, const double* h_xverts, const int32_t* h_geom_dofmap,
                     int use_fabs, int clamp, double* h_G, double* h_detJ)
 {
@@ -243,25 +276,20 @@ int wf_geometry_hex(int P, int ncells, int nverts, const double* h_xverts, const
     set_error("wf_geometry_hex: degree must be 1..7");
     return WF_ERR_UNSUPPORTED;
   }
-  WF_REQUIRE(ncells >= 0 && nverts >= 0 && h_xverts && h_geom_dofmap, "wf_geometry_hex: bad arguments");
-  for (size_t e = 0; e < (size_t)ncells * 8; ++e)
-    WF_REQUIRE(h_geom_dofmap[e] >= 0 && h_geom_dofmap[e] < nverts, "wf_geometry_hex: vertex index out of range");
-  const size_t nq = (size_t)(P + 1) * (P + 1) * (P + 1);
-  Scratch<double> d_x, d_pts, d_wts, d_G, d_det;
-  Scratch<int32_t> d_gd;
-  int rc;
-  if ((rc = dev_upload(&d_x.p, h_xverts, (size_t)nverts * 3, nullptr)) != WF_OK) return rc;
-  if ((rc = dev_upload(&d_gd.p, h_geom_dofmap, (size_t)ncells * 8, nullptr)) != WF_OK) return rc;
-  if ((rc = upload_tables(P, d_pts, d_wts)) != WF_OK) return rc;
-  if (h_G && (rc = dev_alloc(&d_G.p, (size_t)ncells * nq * 9, nullptr)) != WF_OK) return rc;
-  if (h_detJ && (rc = dev_alloc(&d_det.p, (size_t)ncells * nq, nullptr)) != WF_OK) return rc;
-  if ((rc = launch_geometry_hex(P, ncells, d_x.p, d_gd.p, d_pts.p, d_wts.p, use_fabs, clamp, d_G.p, nullptr,
-                                d_det.p, nullptr)) != WF_OK)
-    return rc;
-  WF_HIP_CHECK(hipDeviceSynchronize());
-  if (h_G) WF_HIP_CHECK(hipMemcpy(h_G, d_G.p, (size_t)ncells * nq * 9 * sizeof(double), hipMemcpyDeviceToHost));
-  if (h_detJ) WF_HIP_CHECK(hipMemcpy(h_detJ, d_det.p, (size_t)ncells * nq * sizeof(double), hipMemcpyDeviceToHost));
-  return WF_OK;
+  const int n = P + 1;
+  std::vector<double> pts(n), wts(n);
+  gll_points_weights(n, pts.data(), wts.data());
+  return geometry_hex_rule(n, pts.data(), wts.data(), ncells, nverts, h_xverts, h_geom_dofmap, use_fabs, clamp, h_G,
+                           h_detJ, "wf_geometry_hex");
+}
+
+int wf_geometry_hex_rule(int ncells, int nverts, const double* h_xverts, const int32_t* h_geom_dofmap, int nq1,
+                         const double* h_points1, const double* h_weights1, int use_fabs, int clamp, double* h_G,
+                         double* h_detJ)
+{
+  WF_REQUIRE(nq1 >= 1 && nq1 <= WF_MAX_QUAD_POINTS && h_points1 && h_weights1, "wf_geometry_hex_rule: bad rule");
+  return geometry_hex_rule(nq1, h_points1, h_weights1, ncells, nverts, h_xverts, h_geom_dofmap, use_fabs, clamp, h_G,
+                           h_detJ, "wf_geometry_hex_rule");
 }
 
 // ---- operators -------------------------------------------------------------
@@ -417,7 +445,8 @@ int wf_op_create(const wf_op_desc* desc, wf_op** out)
     int nq1 = n;
     if (desc->kind == WF_OP_MASS_DENSE) {
       WF_REQUIRE(desc->h_phi1 && desc->nq1 >= 1 && desc->nq1 <= 16, "wf_op_create: dense mass needs phi1[nq1][P+1]");
-      WF_REQUIRE(desc->h_detJ, "wf_op_create: dense mass needs h_detJ[ncells][nq1^3]");
+      WF_REQUIRE(desc->h_detJ || (have_mesh && desc->h_qpts1 && desc->h_qwts1),
+                 "wf_op_create: dense mass needs h_detJ[ncells][nq1^3] or the mesh and the 1-D rule (h_qpts1, h_qwts1)");
       nq1 = desc->nq1;
       if ((rc = dev_upload(&op->d_phi1, desc->h_phi1, (size_t)nq1 * n, &op->device_bytes)) != WF_OK) return rc;
     }
@@ -441,6 +470,16 @@ int wf_op_create(const wf_op_desc* desc, wf_op** out)
     }
     if (desc->h_detJ) {
       if ((rc = dev_upload(&op->d_detJ, h_detJ, ncells * op->nq, &op->device_bytes)) != WF_OK) return rc;
+    } else if (have_mesh && desc->kind == WF_OP_MASS_DENSE) {
+      // det J * w at the caller's tensor rule (precompute.hpp:49-116, mass.hpp:35-39)
+      Scratch<double> d_qp, d_qw;
+      if ((rc = dev_upload(&d_qp.p, desc->h_qpts1, (size_t)nq1, nullptr)) != WF_OK) return rc;
+      if ((rc = dev_upload(&d_qw.p, desc->h_qwts1, (size_t)nq1, nullptr)) != WF_OK) return rc;
+      if ((rc = dev_alloc(&op->d_detJ, ncells * op->nq, &op->device_bytes)) != WF_OK) return rc;
+      if ((rc = launch_geometry_hex(nq1 - 1, desc->ncells, d_x.p, d_gd.p, d_qp.p, d_qw.p, use_fabs, 0, nullptr, nullptr,
+                                    op->d_detJ, nullptr)) != WF_OK)
+        return rc;
+      WF_HIP_CHECK(hipDeviceSynchronize());
     } else if (have_mesh) {
       if ((rc = dev_alloc(&op->d_detJ, ncells * nd, &op->device_bytes)) != WF_OK) return rc;
       if ((rc = launch_geometry_hex(P, desc->ncells, d_x.p, d_gd.p, d_pts.p, d_wts.p, use_fabs, 0, nullptr, nullptr,

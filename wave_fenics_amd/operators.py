@@ -76,6 +76,44 @@ def tabulate_dense(p: int):
     return np.arange(nd, dtype=np.int32), table
 
 
+_QUAD = {"gll": _lib.WF_QUAD_GLL, "gauss_jacobi": _lib.WF_QUAD_GAUSS_JACOBI}
+_VARIANT = {"gll_warped": _lib.WF_VARIANT_GLL_WARPED, "gll": _lib.WF_VARIANT_GLL_WARPED, "equispaced": _lib.WF_VARIANT_EQUISPACED}
+
+
+def quadrature_1d(quad: str, degree: int):
+    """basix::quadrature::make_quadrature(quad, interval, degree) on [0,1]: (points, weights).
+    "gauss_jacobi" has (degree+2)//2 points, "gll" (degree+4)//2 (precompute.hpp:183-184,
+    operators.hpp:19)."""
+    n = ctypes.c_int(0)
+    pts, wts = np.zeros(_lib.WF_MAX_QUAD_POINTS), np.zeros(_lib.WF_MAX_QUAD_POINTS)
+    check(lib().wf_quadrature_1d(_QUAD[quad], int(degree), ctypes.byref(n), _dp(pts), _dp(wts)))
+    return pts[: n.value].copy(), wts[: n.value].copy()
+
+
+def tabulate_1d(p: int, points, derivative: int = 0, variant: str = "gll_warped"):
+    """tabulate_1d(p, q, derivative) of common/precompute.hpp:179-189 at given points:
+    table[q][a] = l_a(x_q) or l_a'(x_q) for the degree-p Lagrange basis of `variant`."""
+    pts = np.ascontiguousarray(points, dtype=np.float64)
+    out = np.zeros((pts.size, p + 1))
+    check(lib().wf_tabulate_1d(p, _VARIANT[variant], pts.size, _dp(pts), int(derivative), _dp(out)))
+    return out
+
+
+def compute_geometry_rule(mesh, points1, weights1, use_fabs: bool = False, clamp: bool = False, want_G: bool = False):
+    """compute_jacobian / _determinant / compute_geometrical_factor of
+    common/precompute.hpp:49-176 at the tensor rule points1^3: (G or None, detJ*w)."""
+    pts = np.ascontiguousarray(points1, dtype=np.float64)
+    wts = np.ascontiguousarray(weights1, dtype=np.float64)
+    nq = pts.size ** 3
+    x = np.ascontiguousarray(mesh.x, dtype=np.float64)
+    gd = np.ascontiguousarray(mesh.geom_dofmap, dtype=np.int32)
+    G = np.zeros((mesh.ncells, nq, 3, 3)) if want_G else None
+    detJ = np.zeros((mesh.ncells, nq))
+    check(lib().wf_geometry_hex_rule(mesh.ncells, x.shape[0], _dp(x), _ip(gd), pts.size, _dp(pts), _dp(wts),
+                                     int(use_fabs), int(clamp), _dp(G), _dp(detJ)))
+    return G, detJ
+
+
 def precompute_geometric_data(mesh, p: int, use_fabs: bool = True, clamp: bool = True, want_G: bool = True):
     """precompute_geometric_data (common/precomputation.hpp:18-110) on the device;
     returns host arrays (G[ncells][nq][3][3], detJ[ncells][nq])."""
@@ -271,23 +309,44 @@ class SpectralMassOperator(MassOperatorLumped):
 
 class MassOperator(_Operator):
     """MassOperator(V, element, quad_type, qd) -- common/cuda/mass.hpp:18-107:
-    y += Phi^T diag(detJ w) Phi x with a tensor-product rule.  `phi1` is the 1-D
-    interpolation matrix [nq1][P+1] of the element at the 1-D rule's points and
-    detJ [ncells][nq1^3] the scaled determinants (mass.hpp:35-39)."""
+    y += Phi^T diag(detJ w) Phi x with a tensor-product rule.
 
-    def __init__(self, V: FunctionSpace, degree: int, phi1: np.ndarray, detJ: np.ndarray, perm=None):
+    Either the reference's arguments -- the element as (degree, variant in
+    {"gll_warped", "equispaced"}), quad in {"gll", "gauss_jacobi"} and the quadrature
+    degree qdegree (mass.hpp:20-21; demo/gpu_operator/main.cpp:66-68,96-99 uses
+    equispaced + gauss_jacobi of degree 2P) -- from which the 1-D table
+    (tabulate_1d) and det J * w at the rule's points (on the device) are built; or
+    explicit tables: `phi1` [nq1][P+1] and `detJ` [ncells][nq1^3] (mass.hpp:35-39)."""
+
+    def __init__(self, V: FunctionSpace, degree: int, phi1: np.ndarray | None = None, detJ: np.ndarray | None = None,
+                 perm=None, variant: str = "gll_warped", quad: str = "gll", qdegree: int | None = None):
         super().__init__()
         d, keep = _base_desc(V, _lib.WF_OP_MASS_DENSE, degree, perm)
+        if phi1 is None:
+            if qdegree is None:
+                qdegree = degree + 1 if degree > 1 else degree      # gpu_operator_monolithic/main.cpp:95
+            pts, wts = quadrature_1d(quad, qdegree)
+            phi1 = tabulate_1d(degree, pts, 0, variant)
+            self.points1, self.weights1 = pts, wts
         p1 = np.ascontiguousarray(phi1, dtype=np.float64)
-        Dc = np.ascontiguousarray(detJ, dtype=np.float64)
         if p1.ndim != 2 or p1.shape[1] != degree + 1:
             raise _lib.WavehipError("phi1 must be [nq1][degree+1]")
-        if Dc.size != V.mesh.ncells * p1.shape[0] ** 3:
-            raise _lib.WavehipError("detJ must be [ncells][nq1^3]")
-        keep += [p1, Dc]
+        keep.append(p1)
         d.nq1 = p1.shape[0]
         d.h_phi1 = _dp(p1)
-        d.h_detJ = _dp(Dc)
+        if detJ is not None:
+            Dc = np.ascontiguousarray(detJ, dtype=np.float64)
+            if Dc.size != V.mesh.ncells * p1.shape[0] ** 3:
+                raise _lib.WavehipError("detJ must be [ncells][nq1^3]")
+            keep.append(Dc)
+            d.h_detJ = _dp(Dc)
+        else:
+            if not hasattr(self, "points1"):
+                raise _lib.WavehipError("MassOperator: explicit phi1 needs detJ")
+            _attach_mesh(d, V, keep)
+            qp, qw = np.ascontiguousarray(self.points1), np.ascontiguousarray(self.weights1)
+            keep += [qp, qw]
+            d.h_qpts1, d.h_qwts1 = _dp(qp), _dp(qw)
         self._create(d, keep)
 
 
