@@ -17,7 +17,14 @@
  *   - stream is a hipStream_t passed as void* (NULL = default stream); all
  *     device work is stream-ordered and asynchronous, nothing synchronises
  *     except wf_sync and the setup calls that read host memory.
- *   - element-local tensor ordering l = i + n*(j + n*k), n = P+1, i along x.
+ *   - element-local tensor ordering l = i + n*(j + n*k), n = P+1, i along x (x FASTEST).
+ *     This is the order of every per-dof / per-point array handed over: the tensor side
+ *     of h_perm, h_dofmap when h_perm is NULL, the point index q of h_G [c][q][3][3] and
+ *     h_detJ [c][q], and the vertex index v = a + 2b + 4c of h_geom_dofmap.  A caller whose
+ *     tensor order is x SLOWEST (Basix' get_tensor_product_representation, whose perm the
+ *     reference uses as is, common/permute.hpp:12-17, spectral_mass.hpp:36-38) sets
+ *     WF_FLAG_TENSOR_X_SLOWEST; pairing an x-slowest index with this engine's x-fastest
+ *     geometry silently mixes G_xx with G_zz on any non-cubic cell.
  */
 #ifndef WAVEHIP_H
 #define WAVEHIP_H
@@ -118,6 +125,12 @@ typedef enum {
   WF_FLAG_NONE = 0,
   WF_FLAG_NO_FABS = 1,     /* detJ keeps its sign (spectral_mass.hpp:58-64)    */
   WF_FLAG_NO_CLAMP = 2,    /* skip the -1/0/1 clamp of G                        */
+  WF_FLAG_TENSOR_X_SLOWEST = 8, /* the caller's tensor index -- the domain of h_perm (or of
+                              h_dofmap when h_perm is NULL) and the point index of h_G /
+                              h_detJ -- is l' = (i n + j) n + k with i along x, the order of
+                              Basix' tensor-product factorisation, instead of the engine's
+                              l = i + n (j + n k).  The 3x3 axes of G are reference axes
+                              0, 1, 2 = x, y, z in both conventions.                   */
   WF_FLAG_MASS_ELEMENTWISE = 4 /* lumped mass with a dofmap: apply as the reference's
                               gather * detJ -> scatter-add per cell
                               (spectral_mass.hpp:84-89) instead of the pre-assembled

@@ -116,6 +116,8 @@ struct Space {
   std::int32_t ndofs = 0;                   // index_map->size_local() + num_ghosts()
   const std::int32_t* dofmap = nullptr;     // V->dofmap()->list().array().data(), [ncells][nd]
   const std::int32_t* perm = nullptr;       // element.get_tensor_product_representation()[0] perm, or nullptr
+  int tensor_flags = 0;                     // WF_FLAG_TENSOR_X_SLOWEST when perm (or the dofmap, or handed-over
+                                            // G / detJ) is in Basix' tensor order l' = (i n + j) n + k
   std::int32_t nverts = 0;
   const double* x = nullptr;                // mesh->geometry().x().data(), [nverts][3]
   const std::int32_t* geom_dofmap = nullptr;// mesh->geometry().dofmap().array().data(), [ncells][8]
@@ -160,6 +162,7 @@ protected:
     d.ndofs = V.ndofs;
     d.h_dofmap = V.dofmap;
     d.h_perm = V.perm;
+    d.flags = V.tensor_flags;
     d.nverts = V.nverts;
     d.h_xverts = V.x;
     d.h_geom_dofmap = V.geom_dofmap;
@@ -192,7 +195,7 @@ public:
   MassOperatorLumped(const Space& V, int bdegree, int flags = WF_FLAG_NONE)
   {
     wf_op_desc d = base_desc(V, WF_OP_MASS_LUMPED, bdegree);
-    d.flags = flags;
+    d.flags |= flags;
     check(wf_op_create(&d, &_op));
   }
 };

@@ -289,6 +289,63 @@ def test_dense_mass_vs_oracle(gpu, oracle, p, variant, quad, qd):
     assert np.abs(G - np.swapaxes(G, 2, 3)).max() <= 1e-14 * np.abs(G).max()
 
 
+@pytest.mark.parametrize("p", [2, 3, 4])
+def test_x_slowest_tensor_order(gpu, oracle, p):
+    """The DOLFINx-facing axis-order hazard: a caller whose tensor index is x-SLOWEST
+    (Basix' tensor-product factorisation, l' = (i n + j) n + k) hands over its dofmap,
+    an element permutation defined on that order, and G / detJ with points in that
+    order.  With WF_FLAG_TENSOR_X_SLOWEST the result must equal the dense oracle on an
+    anisotropic perturbed mesh (where pairing the wrong axes shows at once); without the
+    flag the same inputs must NOT match (the hazard is real, the test can see it)."""
+    import wave_fenics_amd as w
+    from wave_fenics_amd import _lib
+    n = (3, 2, 2)
+    hi = (1.0, 0.37, 2.3)                                   # anisotropic: G_xx != G_yy != G_zz
+    om = oracle.create_box(n, p, hi=hi, perturb=0.2)
+    mesh = w.BoxMesh(om.n, om.x.copy(), om.geom_dofmap.copy(), (0.0, 0.0, 0.0), hi)
+    nn = p + 1
+    nd = nn ** 3
+    k, j, i = np.meshgrid(np.arange(nn), np.arange(nn), np.arange(nn), indexing="ij")
+    fast = (i + nn * (j + nn * k)).reshape(-1)              # engine index of (i, j, k)
+    slow = ((i * nn + j) * nn + k).reshape(-1)              # Basix-style index of the same (i, j, k)
+    to_slow = np.empty(nd, dtype=np.int64)
+    to_slow[slow] = fast                                    # to_slow[l'] = l
+    rng = np.random.default_rng(12)
+    eperm = rng.permutation(nd).astype(np.int32)            # element (Basix dof) order <-> x-slowest tensor order
+    # caller's arrays: dofmap in element order with dm_elem[c][eperm[l']] = dm_tensor_xslow[c][l']
+    dm_xs = om.dofmap[:, to_slow]
+    dm_elem = np.empty_like(dm_xs)
+    dm_elem[:, eperm] = dm_xs
+    K = oracle.StiffnessOperator(om, p)
+    M = oracle.MassOperatorCPU(om, p)
+    G_xs = np.ascontiguousarray(K.G[:, to_slow])            # point index in x-slowest order, 3x3 axes unchanged
+    detJ_xs = np.ascontiguousarray(M.detJ[:, to_slow])
+    x = rng.uniform(-1, 1, om.ndofs)
+    yK, yM = np.zeros(om.ndofs), np.zeros(om.ndofs)
+    K(x, yK)
+    M(x, yM)
+    V = w.FunctionSpace(mesh, p, np.ascontiguousarray(dm_elem), w.IndexMap(om.ndofs), om.lattice, structured=False)
+    F = _lib.WF_FLAG_TENSOR_X_SLOWEST
+    for kw in (dict(G=G_xs, perm=eperm), dict(perm=eperm)):            # handed-over G / device geometry
+        y = dev(np.zeros(om.ndofs), gpu)
+        w.StiffnessOperator(V, p, {"c0": 1500.0}, structured=False, flags=F, **kw)(dev(x, gpu), y)
+        assert relerr(y.cpu().numpy(), yK) <= TOL
+    for kw in (dict(detJ=detJ_xs, perm=eperm), dict(perm=eperm)):
+        for fl in (F, F | _lib.WF_FLAG_MASS_ELEMENTWISE):
+            y = dev(np.zeros(om.ndofs), gpu)
+            w.MassOperatorLumped(V, p, structured=False, flags=fl, **kw)(dev(x, gpu), y)
+            assert relerr(y.cpu().numpy(), yM) <= 1e-14
+    # no perm: the dofmap itself is in x-slowest tensor order
+    V2 = w.FunctionSpace(mesh, p, np.ascontiguousarray(dm_xs), w.IndexMap(om.ndofs), om.lattice, structured=False)
+    y = dev(np.zeros(om.ndofs), gpu)
+    w.StiffnessOperator(V2, p, {"c0": 1500.0}, G=G_xs, structured=False, flags=F)(dev(x, gpu), y)
+    assert relerr(y.cpu().numpy(), yK) <= TOL
+    # the hazard: the same x-slowest inputs without the flag give a different operator
+    y = dev(np.zeros(om.ndofs), gpu)
+    w.StiffnessOperator(V2, p, {"c0": 1500.0}, structured=False)(dev(x, gpu), y)
+    assert relerr(y.cpu().numpy(), yK) > 1e-3
+
+
 def test_gather_scatter_transform(gpu, oracle):
     """demo/gpu_scatter_local/main.cpp:70,84-90: gather(iota) == dofmap, exactly."""
     import torch

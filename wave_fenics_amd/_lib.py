@@ -72,7 +72,7 @@ WF_COMM_ID_BYTES = 128
 WF_SUM, WF_MAX = 0, 1
 WF_UPDATER_DEFAULT, WF_UPDATER_INLINE = 0, 1
 WF_OP_STIFFNESS, WF_OP_MASS_LUMPED, WF_OP_MASS_DENSE = 0, 1, 2
-WF_FLAG_NONE, WF_FLAG_NO_FABS, WF_FLAG_NO_CLAMP, WF_FLAG_MASS_ELEMENTWISE = 0, 1, 2, 4
+WF_FLAG_NONE, WF_FLAG_NO_FABS, WF_FLAG_NO_CLAMP, WF_FLAG_MASS_ELEMENTWISE, WF_FLAG_TENSOR_X_SLOWEST = 0, 1, 2, 4, 8
 WF_PART_ALL, WF_PART_INTERIOR, WF_PART_INTERFACE, WF_PART_INTERIOR_A, WF_PART_INTERIOR_B = 0, 1, 2, 3, 4
 
 # every symbol include/wavehip.h declares: name -> (restype, argtypes)

@@ -326,6 +326,34 @@ int wf_op_create(const wf_op_desc* desc, wf_op** out)
       WF_REQUIRE(desc->h_geom_dofmap[e] >= 0 && desc->h_geom_dofmap[e] < desc->nverts,
                  "wf_op_create: vertex index out of range");
 
+  // Axis order of the caller's tensor indices.  The engine's is x-FASTEST: l = i + n (j + n k),
+  // i along x.  With WF_FLAG_TENSOR_X_SLOWEST the caller's tensor index (the domain of h_perm
+  // -- or of the dofmap itself when h_perm is NULL -- and the point index of h_G / h_detJ) is
+  // l' = (i n + j) n + k, the order of Basix' tensor-product factorisation.  Both are folded
+  // into one element permutation and one point permutation here; the 3x3 axes of G keep
+  // their meaning (reference axes 0, 1, 2 = x, y, z in both conventions).
+  const bool xslow = (desc->flags & WF_FLAG_TENSOR_X_SLOWEST) != 0;
+  std::vector<int32_t> eff_perm;
+  const int32_t* use_perm = desc->h_perm;
+  if (xslow) {
+    eff_perm.resize(nd);
+    for (int k = 0; k < n; ++k)
+      for (int j = 0; j < n; ++j)
+        for (int i = 0; i < n; ++i) {
+          const int lp = (i * n + j) * n + k;
+          eff_perm[i + n * (j + n * k)] = desc->h_perm ? desc->h_perm[lp] : lp;
+        }
+    use_perm = eff_perm.data();
+  }
+  // point permutation of per-point input arrays: engine point q <- caller point qmap[q]
+  auto make_qmap = [&](int m) {
+    std::vector<int32_t> q((size_t)m * m * m);
+    for (int k = 0; k < m; ++k)
+      for (int j = 0; j < m; ++j)
+        for (int i = 0; i < m; ++i) q[i + m * (j + m * k)] = xslow ? (i * m + j) * m + k : i + m * (j + m * k);
+    return q;
+  };
+
   std::unique_ptr<wf_op, void (*)(wf_op*)> op(new wf_op, free_op);
   op->kind = desc->kind;
   op->P = P;
@@ -356,27 +384,31 @@ int wf_op_create(const wf_op_desc* desc, wf_op** out)
   std::vector<double> p_detJ;
   const int32_t* h_geom_dofmap = desc->h_geom_dofmap;
   const double* h_detJ = desc->h_detJ;
-  if (!identity_cells) {
-    if (have_mesh) {
-      p_geom.resize(ncells * 8);
-      for (size_t c = 0; c < ncells; ++c) std::memcpy(&p_geom[c * 8], desc->h_geom_dofmap + (size_t)cperm[c] * 8, 8 * sizeof(int32_t));
-      h_geom_dofmap = p_geom.data();
+  if (!identity_cells && have_mesh) {
+    p_geom.resize(ncells * 8);
+    for (size_t c = 0; c < ncells; ++c) std::memcpy(&p_geom[c * 8], desc->h_geom_dofmap + (size_t)cperm[c] * 8, 8 * sizeof(int32_t));
+    h_geom_dofmap = p_geom.data();
+  }
+  if (desc->h_detJ && (!identity_cells || xslow)) {
+    const int mq = desc->kind == WF_OP_MASS_DENSE ? desc->nq1 : n;
+    WF_REQUIRE(mq >= 1 && mq <= 16, "wf_op_create: bad nq1");
+    const size_t nqm = (size_t)mq * mq * mq;
+    const std::vector<int32_t> qm = make_qmap(mq);
+    p_detJ.resize(ncells * nqm);
+    for (size_t c = 0; c < ncells; ++c) {
+      const double* src = desc->h_detJ + (size_t)cperm[c] * nqm;
+      for (size_t q = 0; q < nqm; ++q) p_detJ[c * nqm + q] = src[qm[q]];
     }
-    if (desc->h_detJ) {
-      const size_t nqm = desc->kind == WF_OP_MASS_DENSE ? (size_t)desc->nq1 * desc->nq1 * desc->nq1 : (size_t)nd;
-      p_detJ.resize(ncells * nqm);
-      for (size_t c = 0; c < ncells; ++c) std::memcpy(&p_detJ[c * nqm], desc->h_detJ + (size_t)cperm[c] * nqm, nqm * sizeof(double));
-      h_detJ = p_detJ.data();
-    }
+    h_detJ = p_detJ.data();
   }
 
   // tensor-ordered dofmap (permute.hpp:10-27 when the caller's element ordering differs)
   {
     std::vector<int32_t> tmp, tmp2;
     const int32_t* src = desc->h_dofmap;
-    if (desc->h_perm && ncells) {
+    if (use_perm && ncells) {
       tmp.resize(ncells * nd);
-      if ((rc = wf_reorder_dofmap(desc->ncells, nd, desc->h_perm, desc->h_dofmap, tmp.data())) != WF_OK) return rc;
+      if ((rc = wf_reorder_dofmap(desc->ncells, nd, use_perm, desc->h_dofmap, tmp.data())) != WF_OK) return rc;
       src = tmp.data();
     }
     if (!identity_cells) {
@@ -421,10 +453,13 @@ int wf_op_create(const wf_op_desc* desc, wf_op** out)
       for (size_t c0 = 0; c0 < ncells; c0 += slab_cells) {
         const size_t nc = std::min(slab_cells, ncells - c0);
         const double* hsrc = desc->h_G + c0 * nd * 9;
-        if (!identity_cells) {
+        if (!identity_cells || xslow) {
+          const std::vector<int32_t> qm = make_qmap(n);
           slab.resize(nc * nd * 9);
-          for (size_t c = 0; c < nc; ++c)
-            std::memcpy(&slab[c * nd * 9], desc->h_G + (size_t)cperm[c0 + c] * nd * 9, (size_t)nd * 9 * sizeof(double));
+          for (size_t c = 0; c < nc; ++c) {
+            const double* gsrc = desc->h_G + (size_t)cperm[c0 + c] * nd * 9;
+            for (int q = 0; q < nd; ++q) std::memcpy(&slab[(c * nd + q) * 9], gsrc + (size_t)qm[q] * 9, 9 * sizeof(double));
+          }
           hsrc = slab.data();
         }
         WF_HIP_CHECK(hipMemcpy(d_G9.p, hsrc, nc * nd * 9 * sizeof(double), hipMemcpyHostToDevice));
