@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--size", type=int, default=54)
     ap.add_argument("--degree", type=int, default=4)
     ap.add_argument("--unfused", action="store_true")
+    ap.add_argument("--periodic", default="", help="axes identified with their opposite face (one rank: RCCL exchange with itself)")
     args = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -46,8 +47,9 @@ def main():
             dist.init_process_group(backend)
     p, n = args.degree, args.size
     L = 0.1
-    part = create_distributed_box(n, p, world, rank, hi=(L, L, L))
-    updater = VectorUpdater(part, device=dev) if world > 1 else None
+    periodic = tuple(c in args.periodic for c in "xyz")
+    part = create_distributed_box(n, p, world, rank, hi=(L, L, L), periodic=periodic)
+    updater = VectorUpdater(part, device=dev) if (world > 1 or any(periodic)) else None
     eqn = LinearGLLOpt(part.V, p, 1500.0, 0.5e6, 6e4, updater=updater, tags=boundary_tags(part), device=dev)
     dt, _ = cfl_time_step(part.mesh, p, 1500.0, 0.5e6, CFL=0.25)
     eqn.init()
@@ -73,7 +75,8 @@ def main():
         print(json.dumps({"metric": "RK4 time step, P4 hex box, full loop (4 x [ghost fwd, K, boundary, ghost rev, vector algebra])",
                           "ms_per_rk4_step": el / args.steps * 1e3, "dof_stages_per_s": 4.0 * part.size_global * args.steps / el,
                           "n_gpus": world, "global_dofs": part.size_global, "cells_per_gpu": part.mesh.ncells,
-                          "fused": not args.unfused, "finite": ok, "scaling": "weak"}), flush=True)
+                          "fused": not args.unfused, "periodic": args.periodic,
+                          "exchange": updater.transport if updater is not None else None, "finite": ok, "scaling": "weak"}), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

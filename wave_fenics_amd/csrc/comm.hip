@@ -123,9 +123,12 @@ struct wf_updater {
   int flags = 0;
   hipStream_t comm_stream = nullptr;         // the exchange runs here unless WF_UPDATER_INLINE
   hipEvent_t ev_packed = nullptr, ev_done = nullptr;
-  // side stream of wf_op_apply_overlapped
+  // streams of wf_op_apply_overlapped: the halo chain runs on a high-priority side stream,
+  // the interior cells on a stream whose CU mask leaves a few CUs free, so that the small
+  // pack / RCCL / unpack kernels never queue behind the interior's resident workgroups
   hipStream_t side_stream = nullptr;
-  hipEvent_t ev_main = nullptr, ev_side = nullptr;
+  hipStream_t interior_stream = nullptr;      // nullptr: interior runs on the caller's stream
+  hipEvent_t ev_main = nullptr, ev_side = nullptr, ev_interior = nullptr;
 };
 
 namespace {
@@ -141,6 +144,8 @@ void free_updater(wf_updater* u)
   if (u->ev_done) (void)hipEventDestroy(u->ev_done);
   if (u->ev_main) (void)hipEventDestroy(u->ev_main);
   if (u->ev_side) (void)hipEventDestroy(u->ev_side);
+  if (u->ev_interior) (void)hipEventDestroy(u->ev_interior);
+  if (u->interior_stream) (void)hipStreamDestroy(u->interior_stream);
   if (u->comm_stream) (void)hipStreamDestroy(u->comm_stream);
   if (u->side_stream) (void)hipStreamDestroy(u->side_stream);
   delete u;
@@ -387,8 +392,32 @@ int wf_updater_create(wf_comm* comm, const wf_updater_desc* desc, wf_updater** o
     WF_HIP_CHECK(hipMemcpy(u->d_ghost_pos, desc->ghost_positions, (size_t)u->nrecv * sizeof(int32_t), hipMemcpyHostToDevice));
     WF_HIP_CHECK(hipMalloc((void**)&u->d_recv_buffer, (size_t)u->nrecv * sizeof(double)));
   }
-  WF_HIP_CHECK(hipStreamCreateWithFlags(&u->comm_stream, hipStreamNonBlocking));
-  WF_HIP_CHECK(hipStreamCreateWithFlags(&u->side_stream, hipStreamNonBlocking));
+  int prio_low = 0, prio_high = 0;
+  WF_HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
+  WF_HIP_CHECK(hipStreamCreateWithPriority(&u->comm_stream, hipStreamNonBlocking, prio_high));
+  WF_HIP_CHECK(hipStreamCreateWithPriority(&u->side_stream, hipStreamNonBlocking, prio_high));
+  // Optional: CUs kept free of interior workgroups through a CU-masked stream
+  // (WF_OVERLAP_RESERVE_CUS = n).  Measured on MI355X (bench.py --periodic x, ms per step):
+  // n = 0: 0.346, n = 4 or 8: 0.476 -- the halo chain then starts at once (RCCL kernel 12 us instead
+  // of 115 us queued behind the interior's resident workgroups) but every event wait between the
+  // masked queue and the other streams costs 40-60 us.  Off by default.
+  {
+    int reserve = 0;
+    if (const char* e = std::getenv("WF_OVERLAP_RESERVE_CUS")) reserve = std::atoi(e);
+    int dev = 0, ncu = 0;
+    WF_HIP_CHECK(hipGetDevice(&dev));
+    WF_HIP_CHECK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+    if (reserve > 0 && reserve < ncu && !u->send_nb.empty() + !u->recv_nb.empty() > 0) {
+      std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
+      for (int c = 0; c < ncu - reserve; ++c) mask[c / 32] |= 1u << (c % 32);
+      hipStream_t s = nullptr;
+      if (hipExtStreamCreateWithCUMask(&s, (uint32_t)mask.size(), mask.data()) == hipSuccess)
+        u->interior_stream = s;
+      else
+        (void)hipGetLastError();   // not supported here: the interior runs on the caller's stream
+    }
+  }
+  WF_HIP_CHECK(hipEventCreateWithFlags(&u->ev_interior, hipEventDisableTiming));
   WF_HIP_CHECK(hipEventCreateWithFlags(&u->ev_packed, hipEventDisableTiming));
   WF_HIP_CHECK(hipEventCreateWithFlags(&u->ev_done, hipEventDisableTiming));
   WF_HIP_CHECK(hipEventCreateWithFlags(&u->ev_main, hipEventDisableTiming));
@@ -469,7 +498,13 @@ int wf_op_apply_overlapped(wf_op* op, wf_updater* u, double* d_x, double* d_y, v
   if ((rc = fwd_begin(u, d_x, side, true)) != WF_OK || (rc = fwd_end(u, d_x, side, true)) != WF_OK) return rc;
   if ((rc = wf_op_apply_part(op, d_x, d_y, WF_PART_INTERFACE, side)) != WF_OK) return rc;
   if ((rc = rev_begin(u, d_y, side, true)) != WF_OK || (rc = rev_end(u, d_y, side, true)) != WF_OK) return rc;
-  if ((rc = wf_op_apply_part(op, d_x, d_y, WF_PART_INTERIOR, main)) != WF_OK) return rc;
+  if (u->interior_stream) {
+    WF_HIP_CHECK(hipStreamWaitEvent(u->interior_stream, u->ev_main, 0));
+    if ((rc = wf_op_apply_part(op, d_x, d_y, WF_PART_INTERIOR, u->interior_stream)) != WF_OK) return rc;
+    WF_HIP_CHECK(hipEventRecord(u->ev_interior, u->interior_stream));
+    WF_HIP_CHECK(hipStreamWaitEvent(main, u->ev_interior, 0));
+  } else if ((rc = wf_op_apply_part(op, d_x, d_y, WF_PART_INTERIOR, main)) != WF_OK)
+    return rc;
   WF_HIP_CHECK(hipEventRecord(u->ev_side, side));
   WF_HIP_CHECK(hipStreamWaitEvent(main, u->ev_side, 0));
   return WF_OK;
