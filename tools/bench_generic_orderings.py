@@ -35,9 +35,15 @@ def main():
     y = torch.zeros_like(x)
     cperm = rng.permutation(mesh.ncells)
     dperm = rng.permutation(V.ndofs).astype(np.int32)
-    # "DOLFINx-like": cells in blocks of 4^3 visited in random block order, dofs numbered by first touch
-    for name, cp, dp in (("lexicographic", None, None), ("random cell order", cperm, None),
-                         ("random dof numbering", None, dperm), ("both random", cperm, dperm)):
+    # "first touch": dofs numbered in the order a cell-by-cell traversal meets them (what a dofmap
+    # builder that walks the cells produces): local, but not lexicographic
+    flat = V.dofmap.reshape(-1)
+    _, first = np.unique(flat, return_index=True)
+    ft = np.empty(V.ndofs, dtype=np.int32)
+    ft[flat[np.sort(first)]] = np.arange(V.ndofs, dtype=np.int32)
+    for name, cp, dp in (("lexicographic", None, None), ("random cell order", cperm, None), ("first-touch numbering", None, ft),
+                         ("first-touch + random cells", cperm, ft), ("random dof numbering", None, dperm),
+                         ("both random", cperm, dperm)):
         dm = V.dofmap if cp is None else V.dofmap[cp]
         gd = mesh.geom_dofmap if cp is None else mesh.geom_dofmap[cp]
         if dp is not None:
@@ -46,7 +52,7 @@ def main():
         V2 = w.FunctionSpace(m2, p, np.ascontiguousarray(dm), w.IndexMap(V.ndofs), V.lattice, structured=False)
         op = w.StiffnessOperator(V2, p, structured=False)
         t = time_op(op, x, y)
-        print(f"{name:24s} {t:8.3f} ms   {op.alg_bytes()/t/1e6:8.0f} GB/s alg", flush=True)
+        print(f"{name:28s} {t:8.3f} ms   {op.alg_bytes()/t/1e6:8.0f} GB/s alg   frac {op.alg_bytes()/t/1e6/8000:.3f}", flush=True)
         del op
 
 

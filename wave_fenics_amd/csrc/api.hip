@@ -31,6 +31,8 @@ struct wf_op {
   int32_t* d_items[4] = {nullptr, nullptr, nullptr, nullptr};
   int nitems[4] = {0, 0, 0, 0};
   int have_parts = 0;
+  MarchPlanDev plan{};            // lattice columns of the indexed marching kernel (stiffness_march_idx.hip)
+  int have_plan = 0, plan_patterns = 0;
   DenseOpData* dense = nullptr;   // dense simplex operator (stiffness_dense.hip)
   int dense_clamp = 1;
   size_t device_bytes = 0;
@@ -80,6 +82,10 @@ void free_op(wf_op* op)
   (void)hipFree(op->d_uniq);
   (void)hipFree(op->d_loc);
   for (int k = 0; k < 4; ++k) (void)hipFree(op->d_items[k]);
+  (void)hipFree(op->plan.d_item_base);
+  (void)hipFree(op->plan.d_item_pattern);
+  (void)hipFree(op->plan.d_item_layers);
+  (void)hipFree(op->plan.d_pat_off);
   dense_free(op->dense);
   delete op;
 }
@@ -364,6 +370,100 @@ int wf_op_create(const wf_op_desc* desc, wf_op** out)
   op->ndofs = desc->ndofs;
   op->coeff = -1.0 * desc->c0 * desc->c0;   // operators.hpp:115
   int rc;
+
+  // ---- stiffness, default path: indexed marching over lattice columns (generic_plan.cpp) ----
+  {
+    const char* gk = std::getenv("WF_GENERIC");
+    const bool legacy = gk && (std::strcmp(gk, "flat") == 0 || std::strcmp(gk, "u") == 0);
+    if (desc->kind == WF_OP_STIFFNESS && !legacy && P <= 4 && ncells > 0) {
+      WF_REQUIRE(desc->h_G || have_mesh, "wf_op_create: stiffness needs h_G or the mesh (h_xverts, h_geom_dofmap)");
+      // tensor-ordered dofmap in the caller's cell order (permute.hpp:10-27)
+      std::vector<int32_t> tdm;
+      const int32_t* tsrc = desc->h_dofmap;
+      if (use_perm) {
+        tdm.resize(ncells * nd);
+        if ((rc = wf_reorder_dofmap(desc->ncells, nd, use_perm, desc->h_dofmap, tdm.data())) != WF_OK) return rc;
+        tsrc = tdm.data();
+      }
+      static const int kBX[5] = {0, 8, 7, 4, 5}, kBY[5] = {0, 8, 4, 4, 2};   // BX * BY == cells_per_batch(P)
+      const int BX = kBX[P], BY = kBY[P], CB = BX * BY;
+      // layers per work item: as many as leave two workgroups per CU (80 KB of LDS each), at most 12
+      int lz_max = 16, lz_fixed = 0;
+      while (lz_max > 1 && march_idx_lds_bytes(P, BX, BY, lz_max) > (size_t)80 * 1024) --lz_max;
+      if (const char* e = std::getenv("WF_MARCH_LZ")) lz_fixed = std::max(1, std::atoi(e));
+      MarchPlan plan;
+      if ((rc = build_march_plan(P, ncells, tsrc, BX, BY, lz_max, lz_fixed, &plan)) != WF_OK) return rc;
+      if (plan.ok) {
+        const int lz = plan.lz;
+        const size_t nslots = (size_t)plan.nitems * lz * CB;
+        op->plan.nitems = plan.nitems;
+        op->plan.lz = lz;
+        op->plan.tile_size = plan.tile_size;
+        op->plan_patterns = plan.npatterns;
+        if ((rc = dev_upload(&op->plan.d_item_base, plan.item_base.data(), plan.item_base.size(), &op->device_bytes)) != WF_OK) return rc;
+        if ((rc = dev_upload(&op->plan.d_item_pattern, plan.item_pattern.data(), plan.item_pattern.size(), &op->device_bytes)) != WF_OK) return rc;
+        if ((rc = dev_upload(&op->plan.d_item_layers, plan.item_layers.data(), plan.item_layers.size(), &op->device_bytes)) != WF_OK) return rc;
+        if ((rc = dev_upload(&op->plan.d_pat_off, plan.pat_off.data(), plan.pat_off.size(), &op->device_bytes)) != WF_OK) return rc;
+        op->have_plan = 1;
+
+        std::vector<double> D(n * n);
+        gll_derivative_matrix(P, D.data());
+        for (int q = 0; q < n * n; ++q) op->dm.v[q] = D[q];
+        if ((rc = dev_upload(&op->d_D, D.data(), (size_t)n * n, &op->device_bytes)) != WF_OK) return rc;
+
+        // geometry in slot order [item][layer][ly][lx]; missing cells stay zero (they contribute nothing)
+        const size_t g6 = nslots * nd * 6;
+        if ((rc = dev_alloc(&op->d_G6blk, g6, &op->device_bytes)) != WF_OK) return rc;
+        WF_HIP_CHECK(hipMemset(op->d_G6blk, 0, g6 * sizeof(double)));
+        const int use_fabs = (desc->flags & WF_FLAG_NO_FABS) ? 0 : 1;
+        const int clamp = (desc->flags & WF_FLAG_NO_CLAMP) ? 0 : 1;
+        if (desc->h_G) {
+          const std::vector<int32_t> qm = make_qmap(n);
+          const size_t slab_slots = std::max<size_t>(CB, (((size_t)64 << 20) / (nd * 9 * sizeof(double))) / CB * CB);
+          Scratch<double> d_G9;
+          if ((rc = dev_alloc(&d_G9.p, std::min(slab_slots, nslots) * nd * 9, nullptr)) != WF_OK) return rc;
+          std::vector<double> slab;
+          for (size_t s0 = 0; s0 < nslots; s0 += slab_slots) {
+            const size_t ns = std::min(slab_slots, nslots - s0);
+            slab.assign(ns * nd * 9, 0.0);
+            for (size_t q = 0; q < ns; ++q) {
+              const int32_t c = plan.slot_cell[s0 + q];
+              if (c < 0) continue;
+              const double* gsrc = desc->h_G + (size_t)c * nd * 9;
+              for (int pt = 0; pt < nd; ++pt) std::memcpy(&slab[(q * nd + pt) * 9], gsrc + (size_t)qm[pt] * 9, 9 * sizeof(double));
+            }
+            WF_HIP_CHECK(hipMemcpy(d_G9.p, slab.data(), ns * nd * 9 * sizeof(double), hipMemcpyHostToDevice));
+            if ((rc = launch_pack_G6(P, (int)ns, d_G9.p, op->d_G6blk + (s0 / CB) * CB * nd * 6, nullptr)) != WF_OK) return rc;
+            WF_HIP_CHECK(hipDeviceSynchronize());
+          }
+        } else {
+          // one geometry thread per (present cell, point), written to the cell's slot
+          std::vector<int32_t> gd, slot_of;
+          gd.reserve(ncells * 8);
+          slot_of.reserve(ncells);
+          for (size_t q = 0; q < nslots; ++q) {
+            const int32_t c = plan.slot_cell[q];
+            if (c < 0) continue;
+            gd.insert(gd.end(), desc->h_geom_dofmap + (size_t)c * 8, desc->h_geom_dofmap + (size_t)(c + 1) * 8);
+            slot_of.push_back((int32_t)q);
+          }
+          Scratch<double> d_x, d_pts, d_wts;
+          Scratch<int32_t> d_gd, d_slot;
+          if ((rc = dev_upload(&d_x.p, desc->h_xverts, (size_t)desc->nverts * 3, nullptr)) != WF_OK) return rc;
+          if ((rc = dev_upload(&d_gd.p, gd.data(), gd.size(), nullptr)) != WF_OK) return rc;
+          if ((rc = dev_upload(&d_slot.p, slot_of.data(), slot_of.size(), nullptr)) != WF_OK) return rc;
+          if ((rc = upload_tables(P, d_pts, d_wts)) != WF_OK) return rc;
+          if ((rc = launch_geometry_hex_slots(P, (int)slot_of.size(), d_x.p, d_gd.p, d_slot.p, d_pts.p, d_wts.p, use_fabs, clamp,
+                                              op->d_G6blk, nullptr)) != WF_OK)
+            return rc;
+        }
+        WF_HIP_CHECK(hipDeviceSynchronize());
+        *out = op.release();
+        return WF_OK;
+      }
+      // the mesh does not tile into lattice columns: batch kernel below
+    }
+  }
 
   // Internal cell order: cells are summed independently, so the operator may visit
   // them in any order.  Sorting by the smallest dof of each cell puts cells that
@@ -727,6 +827,8 @@ int wf_op_apply(wf_op* op, const double* d_x, double* d_y, void* stream)
   }
   switch (op->kind) {
     case WF_OP_STIFFNESS:
+      if (op->have_plan)
+        return launch_stiffness_march_idx(op->P, 0, op->plan, op->d_G6blk, op->d_D, op->dm, op->coeff, d_x, d_y, s);
       if (op->generic_unique)
         return launch_stiffness_generic_u(op->P, op->ncells, op->d_uoff, op->d_uniq, op->d_loc, op->d_G6blk, op->d_D,
                                           op->dm, op->coeff, d_x, d_y, s);

@@ -53,6 +53,9 @@ int launch_geometry_hex(int P, int ncells, const double* d_xverts, const int32_t
 int launch_geometry_box(int P, int nx, int ny, int nz, int bx, int by, int bz, const double* d_xverts,
                         const double* d_pts, const double* d_wts, int use_fabs, int clamp,
                         double* d_G6blk, double* d_detJ_lattice, hipStream_t s);
+int launch_geometry_hex_slots(int P, int ncells, const double* d_xverts, const int32_t* d_geom_dofmap,
+                              const int32_t* d_slot_of, const double* d_pts, const double* d_wts, int use_fabs,
+                              int clamp, double* d_G6blk, hipStream_t s);
 int launch_pack_G6(int P, int ncells, const double* d_G9, double* d_G6blk, hipStream_t s);
 int launch_stiffness_generic(int P, int ncells, const int32_t* d_dofmap, const double* d_G6blk,
                              const double* d_D, const DMat& dm, double coeff, const double* d_x,
@@ -67,6 +70,24 @@ bool march_variant(int P, int variant, int* bx, int* by);
 int launch_stiffness_march(int P, int variant, int nx, int ny, int nz, int lz, const double* d_G6blk,
                            const double* d_D, const DMat& dm, double coeff, const double* d_x, double* d_y,
                            const int32_t* d_items, int nitems, hipStream_t s);
+// indexed marching kernel for arbitrary dofmaps (generic_plan.cpp, stiffness_march_idx.hip)
+struct MarchPlan {
+  bool ok = false;                      // false: the mesh does not tile into lattice columns
+  int BX = 0, BY = 0, lz = 0, nitems = 0, npatterns = 0, tile_size = 0;
+  std::vector<int32_t> slot_cell;       // [nitems * lz * BX * BY] cell index or -1, slot order [layer][ly][lx]
+  std::vector<int32_t> item_base;       // [nitems] smallest dof of the item
+  std::vector<int32_t> item_pattern;    // [nitems]
+  std::vector<int32_t> item_layers;     // [nitems] non-empty layers (<= lz)
+  std::vector<int32_t> pat_off;         // [npatterns][tile_size] dof - base per tile position, -1 = uncovered
+};
+struct MarchPlanDev {
+  int nitems = 0, lz = 0, tile_size = 0, variant = 0;
+  int32_t *d_item_base = nullptr, *d_item_pattern = nullptr, *d_item_layers = nullptr, *d_pat_off = nullptr;
+};
+int build_march_plan(int P, size_t ncells, const int32_t* tdm, int BX, int BY, int lz_max, int lz_fixed, MarchPlan* plan);
+size_t march_idx_lds_bytes(int P, int BX, int BY, int lz);
+int launch_stiffness_march_idx(int P, int variant, const MarchPlanDev& pd, const double* d_G6blk, const double* d_D,
+                               const DMat& dm, double coeff, const double* d_x, double* d_y, hipStream_t s);
 // dense simplex operator (stiffness_dense.hip)
 struct DenseOpData;
 int dense_setup(int nd, int nq, int ncells, int ndofs, const int32_t* dofmap, const double* dphi,

@@ -152,6 +152,31 @@ __global__ void k_geometry_hex(int n, int CB, int ncells, const double* __restri
   }
 }
 
+// the same for a subset of slots of the blocked layout: cell c of the list goes to slot slot_of[c]
+// (batch = slot / CB); used by the indexed marching operator, whose slot array has gaps
+__global__ void k_geometry_hex_slots(int n, int CB, int ncells, const double* __restrict__ xverts,
+                                     const int32_t* __restrict__ geom_dofmap, const int32_t* __restrict__ slot_of,
+                                     const double* __restrict__ pts, const double* __restrict__ wts, int use_fabs,
+                                     int do_clamp, double* __restrict__ G6blk)
+{
+  const int nd = n * n * n;
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (size_t)ncells * nd) return;
+  const int c = (int)(gid / nd), q = (int)(gid % nd);
+  const int i = q % n, j = (q / n) % n, k = q / (n * n);
+  double xv[8][3];
+  for (int v = 0; v < 8; ++v) {
+    const int32_t vi = geom_dofmap[(size_t)c * 8 + v];
+    xv[v][0] = xverts[(size_t)vi * 3 + 0];
+    xv[v][1] = xverts[(size_t)vi * 3 + 1];
+    xv[v][2] = xverts[(size_t)vi * 3 + 2];
+  }
+  double G9[9], d;
+  hex_point_geometry(xv, pts[i], pts[j], pts[k], wts[i] * wts[j] * wts[k], use_fabs, do_clamp, G9, &d);
+  const int slot = slot_of[c];
+  store_g6(G6blk, n, CB * n * n, slot / CB, k, (slot % CB) * n * n + j * n + i, G9);
+}
+
 // reference-layout G[ncells][nq][3][3] -> blocked symmetric layout (upper triangle)
 __global__ void k_pack_G6(int n, int CB, int ncells, const double* __restrict__ G9in,
                           double* __restrict__ G6blk)
@@ -830,6 +855,19 @@ int launch_geometry_hex(int P, int ncells, const double* d_xverts, const int32_t
   if (N == 0) return WF_OK;
   hipLaunchKernelGGL(k_geometry_hex, dim3(grid_for(N, 256)), dim3(256), 0, s, n, cells_per_batch(P), ncells,
                      d_xverts, d_geom_dofmap, d_pts, d_wts, use_fabs, clamp, d_G9, d_G6blk, d_detJ);
+  WF_LAUNCH_CHECK();
+  return WF_OK;
+}
+
+int launch_geometry_hex_slots(int P, int ncells, const double* d_xverts, const int32_t* d_geom_dofmap,
+                              const int32_t* d_slot_of, const double* d_pts, const double* d_wts, int use_fabs,
+                              int clamp, double* d_G6blk, hipStream_t s)
+{
+  const int n = P + 1;
+  const size_t N = (size_t)ncells * n * n * n;
+  if (N == 0) return WF_OK;
+  hipLaunchKernelGGL(k_geometry_hex_slots, dim3(grid_for(N, 256)), dim3(256), 0, s, n, cells_per_batch(P), ncells,
+                     d_xverts, d_geom_dofmap, d_slot_of, d_pts, d_wts, use_fabs, clamp, d_G6blk);
   WF_LAUNCH_CHECK();
   return WF_OK;
 }

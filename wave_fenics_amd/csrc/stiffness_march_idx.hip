@@ -1,0 +1,223 @@
+// k_stiffness_march_idx<P, BX, BY>: the marching stiffness kernel (stiffness_march.hip) for
+// an ARBITRARY dofmap -- StiffnessOperator::operator(), common/operators.hpp:183-200, on any
+// conforming hexahedral mesh whose cells link up like a lattice (generic_plan.cpp), whatever
+// the cell order and dof numbering.
+//
+// Same structure as the box kernel: a 256-thread workgroup owns a column of BX x BY cells and
+// marches through <= lz layers; the next layer's geometry (48 B per point) and x planes are in
+// flight while the current layer is computed; the z-shared plane is carried in a register; the
+// finished planes go to y with one fp64 atomic per tile dof.  The only difference is where
+// ADDRESSES come from: the column's dof tile [P lz + 1][P BY + 1][P BX + 1] is a table of dof
+// offsets (PATTERN, shared by all work items with the same relative numbering) that is staged
+// in LDS once per work item -- inside the layer loop the only global loads are then the
+// prefetches (vmcnt retires loads in order: an index load consumed inside a layer would have to
+// wait for the geometry prefetch issued before it).
+// HBM-bound; algorithmic bytes ncells (48 nq + 4 nd) + 16 ndofs; the index
+// table costs 4 P (P BX + 1)(P BY + 1) / (BX BY) bytes per cell when it is not L2-resident.
+#include "stiffness_core.h"
+
+namespace wf {
+
+template <int P, int BX, int BY>
+__global__ __launch_bounds__(256, 2) void k_stiffness_march_idx(int lz, int tile_size, const int32_t* __restrict__ item_base,
+                                                                const int32_t* __restrict__ item_pattern,
+                                                                const int32_t* __restrict__ item_layers,
+                                                                const int32_t* __restrict__ pat_off,
+                                                                const double2* __restrict__ G6blk,
+                                                                const double* __restrict__ dD, DMat dm, double coeff,
+                                                                const double* __restrict__ x, double* __restrict__ y)
+{
+  constexpr int n = P + 1, n2 = n * n, nd = n * n2;
+  constexpr int CB = BX * BY, NT = CB * n2;
+  constexpr int TX = P * BX + 1, TY = P * BY + 1, TP = TX * TY;
+  constexpr int NPOS = (P * TP + 255) / 256;        // flush / x-prefetch positions per thread
+  constexpr int NPOS0 = ((P + 1) * TP + 255) / 256; // prologue x positions per thread
+  constexpr int NCP = (TP + 255) / 256;             // positions of one plane per thread
+  static_assert(NT <= 256, "column does not fit a 256-thread workgroup");
+
+  __shared__ __attribute__((aligned(16))) double Ux[(P + 1) * TP];   // x planes of the layer
+  __shared__ __attribute__((aligned(16))) double O[CB * P * n2];     // per-cell results, planes 0..P-1
+  __shared__ __attribute__((aligned(16))) double Fr[CB * nd];
+  __shared__ __attribute__((aligned(16))) double Fs[CB * nd];
+  __shared__ __attribute__((aligned(16))) double sD[n * n];
+  extern __shared__ __attribute__((aligned(16))) int32_t sIdx[];     // [(P lz + 1)][TP] dof offsets of the column, -1 = none
+
+  const int t = threadIdx.x;
+  const size_t item = blockIdx.x;
+  const int nl = item_layers[item];
+  const size_t gbase = (size_t)item_base[item];
+  const int32_t* __restrict__ pat = pat_off + (size_t)item_pattern[item] * tile_size;
+  const bool active = t < NT;
+  const int cl = t / n2, ji = t % n2, j = ji / n, i = ji % n;
+  const int lx = cl % BX, ly = cl / BX;
+
+  double2 gcur[n][3], gnext[n][3];
+  auto load_g = [&](double2 (&g)[n][3], int l) {
+    const double2* gp = G6blk + ((item * lz + l) * n * 3) * (size_t)NT + t;
+#pragma unroll
+    for (int k = 0; k < n; ++k)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) g[k][p] = gp[(size_t)(k * 3 + p) * NT];
+  };
+  // index table first (L2-resident for regular numberings), then the first layer's geometry and
+  // x planes together: one HBM latency in the prologue, not two (loads retire in order)
+  if (t < n * n) sD[t] = dD[t];
+  for (int e = t; e < (P * nl + 1) * TP; e += 256) sIdx[e] = pat[e];
+  __syncthreads();
+  if (active) load_g(gcur, 0);
+  // ---- prologue: x planes 0..P of the first layer -> LDS ------------------------
+#pragma unroll
+  for (int m = 0; m < NPOS0; ++m) {
+    const int pos = t + 256 * m;
+    if (pos < (P + 1) * TP) {
+      const int32_t off = sIdx[pos];
+      Ux[pos] = off >= 0 ? x[gbase + off] : 0.0;
+    }
+  }
+  __syncthreads();
+
+  double carry = 0.0;
+  const double* Uc = Ux + (P * ly) * TX + P * lx;
+
+  for (int l = 0; l < nl; ++l) {
+    const bool has_next = l + 1 < nl;
+    // (a) next layer's x planes and geometry: in flight during this layer's arithmetic
+    double xn[NPOS];
+#pragma unroll
+    for (int m = 0; m < NPOS; ++m) {
+      const int pos = t + 256 * m;
+      xn[m] = 0.0;
+      if (has_next && pos < P * TP) {
+        const int32_t off = sIdx[(P * (l + 1) + 1) * TP + pos];
+        if (off >= 0) xn[m] = x[gbase + off];
+      }
+    }
+    if (has_next && active) load_g(gnext, l + 1);
+
+    // (b) element kernels of the layer
+    double out[n];
+    stiffness_column<P>(Uc, TP, TX, Fr + cl * nd, Fs + cl * nd, sD, dm, gcur, coeff, i, j, active, out);
+    double xcp[NCP];
+#pragma unroll
+    for (int m = 0; m < NCP; ++m) {
+      const int pos = t + 256 * m;
+      xcp[m] = pos < TP ? Ux[P * TP + pos] : 0.0;
+    }
+    if (active) {
+      out[0] += carry;        // z-shared plane: partial sum of the layer below
+      carry = out[P];
+#pragma unroll
+      for (int k = 0; k < P; ++k) O[(cl * P + k) * n2 + ji] = out[k];
+    }
+    __syncthreads();
+
+    // (c) combine the cells of the layer (fixed order) and add the finished planes to y
+#pragma unroll
+    for (int m = 0; m < NPOS; ++m) {
+      const int pos = t + 256 * m;
+      if (pos >= P * TP) continue;
+      const int32_t off = sIdx[(P * l) * TP + pos];
+      if (off < 0) continue;
+      const int pl = pos / TP, r = pos % TP, J = r / TX, I = r % TX;
+      const int ca = I / P, ia = I % P, cb = J / P, jb = J % P;
+      double v = 0.0;
+      if (cb < BY) {
+        if (ca < BX) v += O[((cb * BX + ca) * P + pl) * n2 + jb * n + ia];
+        if (ia == 0 && ca > 0) v += O[((cb * BX + ca - 1) * P + pl) * n2 + jb * n + P];
+      }
+      if (jb == 0 && cb > 0) {
+        if (ca < BX) v += O[(((cb - 1) * BX + ca) * P + pl) * n2 + P * n + ia];
+        if (ia == 0 && ca > 0) v += O[(((cb - 1) * BX + ca - 1) * P + pl) * n2 + P * n + P];
+      }
+      unsafeAtomicAdd(y + gbase + off, v);
+    }
+
+    // (d) rotate the x planes and the geometry registers
+    if (has_next) {
+#pragma unroll
+      for (int m = 0; m < NCP; ++m) {
+        const int pos = t + 256 * m;
+        if (pos < TP) Ux[pos] = xcp[m];
+      }
+#pragma unroll
+      for (int m = 0; m < NPOS; ++m) {
+        const int pos = t + 256 * m;
+        if (pos < P * TP) Ux[TP + pos] = xn[m];
+      }
+#pragma unroll
+      for (int k = 0; k < n; ++k)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) gcur[k][p] = gnext[k][p];
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: the last (carried) plane ------------------------------------
+  if (active) O[cl * n2 + ji] = carry;
+  __syncthreads();
+#pragma unroll
+  for (int m = 0; m < NCP; ++m) {
+    const int pos = t + 256 * m;
+    if (pos >= TP) continue;
+    const int32_t off = sIdx[(P * nl) * TP + pos];
+    if (off < 0) continue;
+    const int J = pos / TX, I = pos % TX;
+    const int ca = I / P, ia = I % P, cb = J / P, jb = J % P;
+    double v = 0.0;
+    if (cb < BY) {
+      if (ca < BX) v += O[(cb * BX + ca) * n2 + jb * n + ia];
+      if (ia == 0 && ca > 0) v += O[(cb * BX + ca - 1) * n2 + jb * n + P];
+    }
+    if (jb == 0 && cb > 0) {
+      if (ca < BX) v += O[((cb - 1) * BX + ca) * n2 + P * n + ia];
+      if (ia == 0 && ca > 0) v += O[((cb - 1) * BX + ca - 1) * n2 + P * n + P];
+    }
+    unsafeAtomicAdd(y + gbase + off, v);
+  }
+}
+
+template <int P, int BX, int BY>
+static int launch_t(const MarchPlanDev& pd, const double* d_G6blk, const double* d_D, const DMat& dm, double coeff,
+                    const double* d_x, double* d_y, hipStream_t s)
+{
+  if (pd.nitems == 0) return WF_OK;
+  const size_t dyn = (size_t)pd.tile_size * sizeof(int32_t);
+  static size_t dyn_set = 0;   // per instantiation: static + dynamic LDS may exceed the 64 KB default limit
+  if (dyn > dyn_set) {
+    WF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stiffness_march_idx<P, BX, BY>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+    dyn_set = dyn;
+  }
+  hipLaunchKernelGGL((k_stiffness_march_idx<P, BX, BY>), dim3((unsigned)pd.nitems), dim3(256), dyn, s, pd.lz, pd.tile_size,
+                     pd.d_item_base, pd.d_item_pattern, pd.d_item_layers, pd.d_pat_off,
+                     reinterpret_cast<const double2*>(d_G6blk), d_D, dm, coeff, d_x, d_y);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error(std::string("stiffness_march_idx launch failed: ") + hipGetErrorString(e));
+    return WF_ERR_HIP;
+  }
+  return WF_OK;
+}
+
+// static LDS of the kernel + the index tile must leave room for two workgroups per CU
+size_t march_idx_lds_bytes(int P, int BX, int BY, int lz)
+{
+  const int n = P + 1, n2 = n * n, nd = n * n2, CB = BX * BY, TP = (P * BX + 1) * (P * BY + 1);
+  return (size_t)((P + 1) * TP + CB * P * n2 + 2 * CB * nd + n * n) * sizeof(double) + (size_t)(P * lz + 1) * TP * sizeof(int32_t);
+}
+
+int launch_stiffness_march_idx(int P, int variant, const MarchPlanDev& pd, const double* d_G6blk, const double* d_D,
+                               const DMat& dm, double coeff, const double* d_x, double* d_y, hipStream_t s)
+{
+  (void)variant;
+  switch (P) {   // the cross-sections with BX * BY == floor(256 / n^2) cells (geometry batch layout)
+    case 1: return launch_t<1, 8, 8>(pd, d_G6blk, d_D, dm, coeff, d_x, d_y, s);
+    case 2: return launch_t<2, 7, 4>(pd, d_G6blk, d_D, dm, coeff, d_x, d_y, s);
+    case 3: return launch_t<3, 4, 4>(pd, d_G6blk, d_D, dm, coeff, d_x, d_y, s);
+    case 4: return launch_t<4, 5, 2>(pd, d_G6blk, d_D, dm, coeff, d_x, d_y, s);
+  }
+  set_error("stiffness_march_idx: compiled for degrees 1..4");
+  return WF_ERR_UNSUPPORTED;
+}
+
+}  // namespace wf
