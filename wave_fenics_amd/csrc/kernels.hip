@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256) void k_stiffness_generic(int ncells, const int
 #pragma unroll
     for (int k = 0; k < n; ++k)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) g[k][p] = gp[(size_t)(k * 3 + p) * NT];
+      for (int p = 0; p < 3; ++p) g[k][p] = load_stream(gp + (size_t)(k * 3 + p) * NT);
   }
   if (t < n * n) sD[t] = dD[t];
 
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(256) void k_stiffness_generic_u(int ncells, const i
 #pragma unroll
     for (int k = 0; k < n; ++k)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) g[k][p] = gp[(size_t)(k * 3 + p) * NT];
+      for (int p = 0; p < 3; ++p) g[k][p] = load_stream(gp + (size_t)(k * 3 + p) * NT);
   }
   if (t < n * n) sD[t] = dD[t];
 
@@ -438,7 +438,7 @@ __global__ __launch_bounds__(256) void k_stiffness_box(int nx, int ny, int nz, i
 #pragma unroll
     for (int k = 0; k < n; ++k)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) g[k][p] = gp[(size_t)(k * 3 + p) * NT];
+      for (int p = 0; p < 3; ++p) g[k][p] = load_stream(gp + (size_t)(k * 3 + p) * NT);
   }
   if (t < n * n) sD[t] = dD[t];
 

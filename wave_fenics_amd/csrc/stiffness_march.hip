@@ -86,10 +86,17 @@ __global__ __launch_bounds__(256, (P <= 4 ? 2 : 1)) void k_stiffness_march(int n
     size_t blk = (size_t)Bx + (size_t)nbx * (By + (size_t)nby * kz);
     if (ablate & 2) blk = 0;   // diagnostic: geometry served from L2
     const double2* gp = G6blk + (blk * n * 3) * (size_t)NT + t;
+    if (ablate & 16) {   // diagnostic: ordinary (temporal) geometry loads
 #pragma unroll
-    for (int k = 0; k < n; ++k)
+      for (int k = 0; k < n; ++k)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) g[k][p] = gp[(size_t)(k * 3 + p) * NT];
+        for (int p = 0; p < 3; ++p) g[k][p] = gp[(size_t)(k * 3 + p) * NT];
+    } else {
+#pragma unroll
+      for (int k = 0; k < n; ++k)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) g[k][p] = load_stream(gp + (size_t)(k * 3 + p) * NT);
+    }
   };
   if (active) load_g(gcur, z0);
   if (t < n * n) sD[t] = dD[t];

@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256, 2) void k_stiffness_march_idx(int lz, int tile
 #pragma unroll
     for (int k = 0; k < n; ++k)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) g[k][p] = gp[(size_t)(k * 3 + p) * NT];
+      for (int p = 0; p < 3; ++p) g[k][p] = load_stream(gp + (size_t)(k * 3 + p) * NT);
   };
   // index table first (L2-resident for regular numberings), then the first layer's geometry and
   // x planes together: one HBM latency in the prologue, not two (loads retire in order)

@@ -2,6 +2,7 @@
 // kernels (a8, a9, a15, a16).  All are HBM-bound; every kernel is
 // a grid-stride loop capped at 256 CUs x 8 workgroups, 16-byte accesses where
 // the operands allow it.
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
@@ -122,15 +123,32 @@ __global__ void k_boundary(int32_t n1, const int32_t* __restrict__ idx1, const d
 // 208 B/dof of the reference's separate copy/axpy/fill/transform passes.
 // u_read/v_read may alias u_/v_ (stages 1..3) or be u0/v0 (stage 0).
 // VEC = 2: 16-byte accesses (all pointers 16-byte aligned, n counted in pairs).
-template <int VEC, bool HAS_NEXT>
+template <int VEC, bool HAS_NEXT, bool NT = false>
 __global__ void __launch_bounds__(256)
 k_rk4_stage(int64_t n, double bdt, double adt_next, double* b, const double* m, const double* vn,
             const double* u_read, const double* v_read, double* u_, double* v_, const double* u0,
             const double* v0, double* un, double* vn_next)
 {
   using V = typename std::conditional<VEC == 2, double2, double>::type;
-  auto ld = [](const double* p, int64_t g) { return reinterpret_cast<const V*>(p)[g]; };
+  typedef double d2v __attribute__((ext_vector_type(2)));
+  // NT: everything except the two vectors the next stiffness apply touches (un, b) bypasses the caches
+  auto ld = [](const double* p, int64_t g) -> V {
+    if constexpr (NT && VEC == 2) {
+      const d2v v = __builtin_nontemporal_load(reinterpret_cast<const d2v*>(p) + g);
+      return make_double2(v.x, v.y);
+    } else
+      return reinterpret_cast<const V*>(p)[g];
+  };
   auto st = [](double* p, int64_t g, V v) { reinterpret_cast<V*>(p)[g] = v; };
+  auto stnt = [](double* p, int64_t g, V v) {
+    if constexpr (NT && VEC == 2) {
+      d2v w;
+      w.x = v.x;
+      w.y = v.y;
+      __builtin_nontemporal_store(w, reinterpret_cast<d2v*>(p) + g);
+    } else
+      reinterpret_cast<V*>(p)[g] = v;
+  };
   for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (int64_t)gridDim.x * blockDim.x) {
     const V bb = ld(b, g), mm = ld(m, g), ku = ld(vn, g), ur = ld(u_read, g), vr = ld(v_read, g);
     V kv, uo, vo, zero;
@@ -156,10 +174,10 @@ k_rk4_stage(int64_t n, double bdt, double adt_next, double* b, const double* m, 
         vn_ = kv * adt_next + c0;
       }
       st(un, g, un_);
-      st(vn_next, g, vn_);
+      stnt(vn_next, g, vn_);
     }
-    st(u_, g, uo);
-    st(v_, g, vo);
+    stnt(u_, g, uo);
+    stnt(v_, g, vo);
     st(b, g, zero);
   }
 }
@@ -267,7 +285,14 @@ int wf_rk4_stage(int64_t n, double bdt, double adt_next, int has_next, double* d
              && aligned(d_v);
   if (has_next) vec = vec && aligned(d_u0) && aligned(d_v0) && aligned(d_un) && aligned(d_vn_next);
   const int64_t nv = vec ? n / 2 : 0;   // pairs handled by the 16-byte kernel; the rest (at most one entry) scalar
+  static const bool nt = std::getenv("WF_STAGE_TEMPORAL") == nullptr;   // default: streaming accesses
 #define WF_STAGE(VEC, NEXT, cnt, off)                                                                          \
+  if (nt && VEC == 2)                                                                                          \
+    hipLaunchKernelGGL((k_rk4_stage<VEC, NEXT, true>), dim3(capped_grid((cnt), 256)), dim3(256), 0, st, (cnt), bdt, \
+                     adt_next, d_b + (off), d_m + (off), d_vn + (off), d_u_read + (off), d_v_read + (off),      \
+                     d_u + (off), d_v + (off), NEXT ? d_u0 + (off) : nullptr, NEXT ? d_v0 + (off) : nullptr,   \
+                     NEXT ? d_un + (off) : nullptr, NEXT ? d_vn_next + (off) : nullptr);                        \
+  else                                                                                                         \
   hipLaunchKernelGGL((k_rk4_stage<VEC, NEXT>), dim3(capped_grid((cnt), 256)), dim3(256), 0, st, (cnt), bdt,     \
                      adt_next, d_b + (off), d_m + (off), d_vn + (off), d_u_read + (off), d_v_read + (off),      \
                      d_u + (off), d_v + (off), NEXT ? d_u0 + (off) : nullptr, NEXT ? d_v0 + (off) : nullptr,   \
