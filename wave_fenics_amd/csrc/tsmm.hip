@@ -13,6 +13,7 @@
 //          formed transposed (A = phi^T, B = in) so that loads and stores stay
 //          contiguous in the cell index.
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -20,20 +21,43 @@ namespace wf {
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
+// k-steps per chunk: the A operands of a chunk are loaded one chunk ahead (two register
+// sets), the B operands (LDS) one k-step ahead, so that no MFMA waits on the load issued
+// just before it.  The LDS table is zero-padded to a whole number of chunks.
+constexpr int kTsmmChunk = 8;
+
+// NT: accumulator tiles (16 columns each) per wave.  (Splitting a cell tile's columns over
+// several waves for small problems was measured at the reference shape 100 000 x 125:
+// no gain -- 0.225 / 0.219 / 0.249 ms per pair of products with 1 / 2 / 4 parts.)
 template <int NT, int LAYOUT>
 __global__ __launch_bounds__(512) void k_tsmm(int64_t ncells, int K, int N, int n0, const double* __restrict__ in,
                                               const double* __restrict__ phi, double* __restrict__ out)
 {
-  extern __shared__ __attribute__((aligned(16))) double sphi[];   // [KP4][16*NT] (zero padded)
-  constexpr int NP = 16 * NT;
-  const int KT = (K + 3) / 4, KP4 = 4 * KT;
+  extern __shared__ __attribute__((aligned(16))) double sphi[];   // [4 * CH * nch][NP] (zero padded)
+  // Row stride of the table in LDS: a wave's B-operand read (ds_read_b64) is served in two 32-lane
+  // halves, each holding two k rows of 16 consecutive doubles; the halves are conflict-free when the
+  // rows fall on different halves of the 64 banks, i.e. NP = 16 (mod 32) doubles.
+  constexpr int NW = 16 * NT;                         // table columns in use
+  constexpr int NP = NW + ((NW & 31) == 16 ? 0 : 16);
+  constexpr int CH = kTsmmChunk;
+  const int KT = (K + 3) / 4, nch = (KT + CH - 1) / CH, rows = 4 * CH * nch;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int lc = lane & 15, lg = lane >> 4;
-  for (int p = t; p < KP4 * NP; p += 512) {
-    const int k = p / NP, n = p % NP;
-    sphi[p] = (k < K && n0 + n < N) ? phi[(size_t)k * N + n0 + n] : 0.0;
+  // table -> LDS: 16 lanes per row segment, all loads of a row in flight together, no integer
+  // division (this prologue is a fixed cost of every launch: 18 432 entries at the reference shape;
+  // as a load -> store chain per entry it took ~35 us of the 106 us kernel)
+  for (int k = t >> 4; k < rows; k += 32) {
+    double v[NP / 16];
+#pragma unroll
+    for (int q = 0; q < NP / 16; ++q) {
+      const int n = (t & 15) + 16 * q;
+      v[q] = (k < K && n < NW && n0 + n < N) ? phi[(size_t)k * N + n0 + n] : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < NP / 16; ++q) sphi[k * NP + (t & 15) + 16 * q] = v[q];
   }
   __syncthreads();
+  const double* bp = sphi + lg * NP + lc;   // B operand of k-step ks, tile nt: bp[(4 ks) NP + 16 nt]
   const int64_t ntiles = (ncells + 15) / 16;
   for (int64_t tile = (int64_t)blockIdx.x * 8 + wave; tile < ntiles; tile += (int64_t)gridDim.x * 8) {
     const int64_t c0 = tile * 16;
@@ -41,34 +65,39 @@ __global__ __launch_bounds__(512) void k_tsmm(int64_t ncells, int K, int N, int 
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[nt] = double4_t{0.0, 0.0, 0.0, 0.0};
     const int64_t c = c0 + lc;
-    // operand loads run a few k-steps ahead of the MFMAs that consume them
-    constexpr int AHEAD = 8;
-    double vbuf[AHEAD];
+    auto load_a = [&](double (&a)[CH], int ch) {
 #pragma unroll
-    for (int a = 0; a < AHEAD; ++a) {
-      const int k = 4 * a + lg;
-      vbuf[a] = (a < KT && k < K && c < ncells) ? (LAYOUT == 0 ? in[c * K + k] : in[(int64_t)k * ncells + c]) : 0.0;
-    }
-    for (int ks0 = 0; ks0 < KT; ks0 += AHEAD) {
+      for (int q = 0; q < CH; ++q) {
+        const int k = 4 * (ch * CH + q) + lg;
+        a[q] = (k < K && c < ncells) ? (LAYOUT == 0 ? in[c * K + k] : in[(int64_t)k * ncells + c]) : 0.0;
+      }
+    };
+    double a_cur[CH], a_nxt[CH], pb[NT], pn[NT];
+    load_a(a_cur, 0);
 #pragma unroll
-     for (int a = 0; a < AHEAD; ++a) {
-      const int ks = ks0 + a;
-      if (ks >= KT) break;
-      const int k = 4 * ks + lg;
-      const double v = vbuf[a];
-      {
-        const int kn = 4 * (ks + AHEAD) + lg;
-        vbuf[a] = (ks + AHEAD < KT && kn < K && c < ncells) ? (LAYOUT == 0 ? in[c * K + kn] : in[(int64_t)kn * ncells + c]) : 0.0;
+    for (int nt = 0; nt < NT; ++nt) pb[nt] = bp[16 * nt];
+    for (int ch = 0; ch < nch; ++ch) {
+      if (ch + 1 < nch) load_a(a_nxt, ch + 1);
+#pragma unroll
+      for (int q = 0; q < CH; ++q) {
+        // next k-step's B operands (the row after the table's last one is never read: ks + 1 < rows / 4)
+        const int ksn = ch * CH + q + 1;
+        if (ksn < nch * CH) {
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) pn[nt] = bp[(size_t)(4 * ksn) * NP + 16 * nt];
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          if (LAYOUT == 0)
+            acc[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[q], pb[nt], acc[nt], 0, 0, 0);   // D[cell][n]
+          else
+            acc[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(pb[nt], a_cur[q], acc[nt], 0, 0, 0);   // D[n][cell]
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) pb[nt] = pn[nt];
       }
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const double p = sphi[k * NP + 16 * nt + lc];
-        if (LAYOUT == 0)
-          acc[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(v, p, acc[nt], 0, 0, 0);   // D[cell][n]
-        else
-          acc[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(p, v, acc[nt], 0, 0, 0);   // D[n][cell]
-      }
-     }
+      for (int q = 0; q < CH; ++q) a_cur[q] = a_nxt[q];
     }
     // D layout: row = lg + 4 r, col = lc
 #pragma unroll
@@ -76,13 +105,13 @@ __global__ __launch_bounds__(512) void k_tsmm(int64_t ncells, int K, int N, int 
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         if (LAYOUT == 0) {
-          const int64_t c = c0 + lg + 4 * r;
+          const int64_t cc = c0 + lg + 4 * r;
           const int n = n0 + 16 * nt + lc;
-          if (c < ncells && n < N) out[c * N + n] = acc[nt][r];
+          if (cc < ncells && n < N) out[cc * N + n] = acc[nt][r];
         } else {
           const int n = n0 + 16 * nt + lg + 4 * r;
-          const int64_t c = c0 + lc;
-          if (c < ncells && n < N) out[(int64_t)n * ncells + c] = acc[nt][r];
+          const int64_t cc = c0 + lc;
+          if (cc < ncells && n < N) out[(int64_t)n * ncells + cc] = acc[nt][r];
         }
       }
   }
@@ -92,21 +121,30 @@ template <int NT>
 static int launch_tsmm_t(int layout, int64_t ncells, int K, int N, int n0, const double* in, const double* phi,
                          double* out, hipStream_t s)
 {
-  const int KP4 = 4 * ((K + 3) / 4);
-  const size_t lds = (size_t)KP4 * 16 * NT * sizeof(double);
+  const int KT = (K + 3) / 4, rows = 4 * kTsmmChunk * ((KT + kTsmmChunk - 1) / kTsmmChunk);
+  const int NW = 16 * NT, NP = NW + ((NW & 31) == 16 ? 0 : 16);
+  const size_t lds = (size_t)rows * NP * sizeof(double);
   if (lds > 160 * 1024) {
-    set_error("wf_tsmm: K too large for the LDS-staged table (K * 128 * 8 B must fit 160 KB)");
+    set_error("wf_tsmm: K too large for the LDS-staged table (K rounded up to 32, times 144 * 8 B, must fit 160 KB)");
     return WF_ERR_UNSUPPORTED;
   }
   const int64_t ntiles = (ncells + 15) / 16;
   const unsigned nb = (unsigned)std::min<int64_t>((ntiles + 7) / 8, 256);
   if (layout == 0) {
     auto kern = k_tsmm<NT, 0>;
-    if (lds > 64 * 1024) WF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    static size_t set0 = 0;
+    if (lds > 64 * 1024 && lds > set0) {
+      WF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      set0 = lds;
+    }
     hipLaunchKernelGGL(kern, dim3(nb), dim3(512), lds, s, ncells, K, N, n0, in, phi, out);
   } else {
     auto kern = k_tsmm<NT, 1>;
-    if (lds > 64 * 1024) WF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    static size_t set1 = 0;
+    if (lds > 64 * 1024 && lds > set1) {
+      WF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      set1 = lds;
+    }
     hipLaunchKernelGGL(kern, dim3(nb), dim3(512), lds, s, ncells, K, N, n0, in, phi, out);
   }
   hipError_t e = hipGetLastError();
