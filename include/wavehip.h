@@ -367,6 +367,25 @@ typedef struct {
 } wf_cg_desc;
 int wf_cg(const wf_cg_desc* desc, double* d_x, const double* d_b, int* iterations, double* rel_residual, void* stream);
 
+/* ---- 8f: mesh / facet-tag input (XDMF + HDF5) -------------------------------
+ * demo/cpu_planar3d/main.cpp:39-45: io::XDMFFile("mesh.xdmf").read_mesh(element, ghost_mode,
+ * "planar3d") and read_meshtags(mesh, "planar3d_boundaries").  Host-only; libhdf5 is bound
+ * at run time.  Hexahedral meshes; vertex orders are converted to the engine's tensor order
+ * (cells: v = a + 2b + 4c, facets: v = a + 2b).  Facet tags come back as the four vertices of
+ * every tagged facet plus its value. */
+typedef struct wf_mesh_file wf_mesh_file;
+int wf_mesh_open(const char* xdmf_path, const char* grid_name, wf_mesh_file** out);
+int wf_mesh_sizes(wf_mesh_file* m, int64_t* nverts, int64_t* ncells);
+int wf_mesh_read(wf_mesh_file* m, double* h_xverts /* [nverts][3] */, int32_t* h_cells /* [ncells][8] */);
+int wf_mesh_tags_size(wf_mesh_file* m, const char* tags_name, int64_t* nfacets);
+int wf_mesh_read_tags(wf_mesh_file* m, const char* tags_name, int32_t* h_facet_verts /* [nfacets][4] */,
+                      int32_t* h_values /* [nfacets] */);
+int wf_mesh_close(wf_mesh_file* m);
+/* writer in the same layout (tags_name may be NULL); <name>.xdmf + <name>.h5 */
+int wf_mesh_write(const char* xdmf_path, const char* grid_name, int64_t nverts, const double* h_xverts, int64_t ncells,
+                  const int32_t* h_cells, const char* tags_name, int64_t nfacets, const int32_t* h_facet_verts,
+                  const int32_t* h_values);
+
 #ifdef __cplusplus
 }
 #endif

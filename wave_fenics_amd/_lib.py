@@ -134,6 +134,13 @@ SIGNATURES = {
     "wf_updater_info": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
     "wf_updater_destroy": (c_int, [c_void_p]),
     "wf_op_apply_overlapped": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "wf_mesh_open": (c_int, [c_char_p, c_char_p, POINTER(c_void_p)]),
+    "wf_mesh_sizes": (c_int, [c_void_p, POINTER(c_int64), POINTER(c_int64)]),
+    "wf_mesh_read": (c_int, [c_void_p, _dp, _ip]),
+    "wf_mesh_tags_size": (c_int, [c_void_p, c_char_p, POINTER(c_int64)]),
+    "wf_mesh_read_tags": (c_int, [c_void_p, c_char_p, _ip, _ip]),
+    "wf_mesh_close": (c_int, [c_void_p]),
+    "wf_mesh_write": (c_int, [c_char_p, c_char_p, c_int64, _dp, c_int64, _ip, c_char_p, c_int64, _ip, _ip]),
     "wf_cg": (c_int, [POINTER(CGDesc), c_void_p, c_void_p, POINTER(c_int), POINTER(c_double), c_void_p]),
     "wf_boundary_apply": (c_int, [c_int32, c_void_p, c_void_p, c_double, c_int32, c_void_p, c_void_p, c_double,
                                   c_void_p, c_void_p, c_void_p]),

@@ -95,18 +95,36 @@ __global__ __launch_bounds__(64 * NW) void k_stiffness_dense(int nd, int nq, int
 #pragma unroll 1
     for (int qt = 0; qt < ((ablate & 8) ? 0 : QT); ++qt) {
       // ---- W = T . U for the rows (dir, 16 qt .. 16 qt + 15) ---------------------
+      // The A operands come from LDS.  Written as "read, then MFMA" the compiler waits for each
+      // read right before the MFMA that uses it (ds_read -> s_waitcnt lgkmcnt(0) -> v_mfma), so
+      // every k-step pays the LDS latency; explicit register double buffers keep the reads of
+      // step s + 1 in flight behind the MFMAs of step s.
       double4_t W[3];
 #pragma unroll
       for (int e = 0; e < 3; ++e) W[e] = double4_t{0.0, 0.0, 0.0, 0.0};
+      const double* Ta = T + (16 * qt + lc) * KP + lg;   // + e NQP KP + 4 ks
+      double ac[3], an[3];
+#pragma unroll
+      for (int e = 0; e < 3; ++e) ac[e] = Ta[e * NQP * KP];
 #pragma unroll
       for (int ks = 0; ks < KT; ++ks) {
-        const int d = 4 * ks + lg;
+        if (ks + 1 < KT) {
 #pragma unroll
-        for (int e = 0; e < 3; ++e) {
-          const double a = T[(e * NQP + 16 * qt + lc) * KP + d];
-          W[e] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, ub[ks], W[e], 0, 0, 0);
+          for (int e = 0; e < 3; ++e) an[e] = Ta[e * NQP * KP + 4 * (ks + 1)];
         }
+        __builtin_amdgcn_sched_barrier(0);   // keep the reads above the MFMAs (the scheduler sinks them otherwise)
+#pragma unroll
+        for (int e = 0; e < 3; ++e) W[e] = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[e], ub[ks], W[e], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < 3; ++e) ac[e] = an[e];
       }
+      // first A operands of the second product: in flight during the lane-local geometry product
+      // (row = e NQP + 16 qt + 4 r + lg, column d = 16 dt + lc; columns >= 4 KT are never stored: pad = 0)
+      const double* Tb = T + (16 * qt + lg) * KP + lc;   // + (e NQP + 4 r) KP + 16 dt
+      double bc[DT], bn[DT];
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) bc[dt] = (16 * dt + lc) < 4 * KT ? Tb[16 * dt] : 0.0;
       // ---- F = coeff * G W (lane-local: the three directions of one (q, cell) share lane and register)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -124,18 +142,21 @@ __global__ __launch_bounds__(64 * NW) void k_stiffness_dense(int nd, int nq, int
       }
       // ---- Y += T^T . F : accumulator register r of a tile is the B operand of k-step r
 #pragma unroll
-      for (int e = 0; e < 3; ++e)
+      for (int st = 0; st < 12; ++st) {
+        const int e = st / 4, r = st % 4;
+        if (st + 1 < 12) {
+          const int en = (st + 1) / 4, rn = (st + 1) % 4;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const double b = W[e][r];
-          const int row = e * NQP + 16 * qt + 4 * r + lg;
-#pragma unroll
-          for (int dt = 0; dt < DT; ++dt) {
-            const int d = 16 * dt + lc;
-            const double a = d < 4 * KT ? T[row * KP + d] : 0.0;
-            Y[dt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, Y[dt], 0, 0, 0);
-          }
+          for (int dt = 0; dt < DT; ++dt) bn[dt] = (16 * dt + lc) < 4 * KT ? Tb[(en * NQP + 4 * rn) * KP + 16 * dt] : 0.0;
         }
+        const double b = W[e][r];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) Y[dt] = __builtin_amdgcn_mfma_f64_16x16x4f64(bc[dt], b, Y[dt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) bc[dt] = bn[dt];
+      }
     }
     // ---- per-batch accumulation over unique dofs, then one atomic per unique dof
     __syncthreads();   // every wave has finished reading Xu
