@@ -465,6 +465,81 @@ int wf_op_create(const wf_op_desc* desc, wf_op** out)
     }
   }
 
+  // ---- dense mass with a square 1-D table: the same lattice columns, mass_column per layer ----
+  {
+    const char* gk = std::getenv("WF_GENERIC");
+    const bool legacy = gk && (std::strcmp(gk, "flat") == 0 || std::strcmp(gk, "u") == 0);
+    if (desc->kind == WF_OP_MASS_DENSE && !legacy && ncells > 0 && desc->nq1 == n && desc->h_phi1
+        && (desc->h_detJ || (have_mesh && desc->h_qpts1 && desc->h_qwts1)) && !std::getenv("WF_MASS_DENSE_GENERIC")) {
+      std::vector<int32_t> tdm;
+      const int32_t* tsrc = desc->h_dofmap;
+      if (use_perm) {
+        tdm.resize(ncells * nd);
+        if ((rc = wf_reorder_dofmap(desc->ncells, nd, use_perm, desc->h_dofmap, tdm.data())) != WF_OK) return rc;
+        tsrc = tdm.data();
+      }
+      static const int kBX[8] = {0, 8, 7, 4, 5, 7, 5, 2}, kBY[8] = {0, 8, 4, 4, 2, 1, 1, 2};
+      const int BX = kBX[P], BY = kBY[P], CB = BX * BY, NTq = CB * n * n;
+      int lz_max = 16, lz_fixed = 0;
+      while (lz_max > 1 && march_idx_lds_bytes(P, BX, BY, lz_max) > (size_t)80 * 1024) --lz_max;
+      if (const char* e = std::getenv("WF_MARCH_LZ")) lz_fixed = std::max(1, std::atoi(e));
+      MarchPlan plan;
+      if ((rc = build_march_plan(P, ncells, tsrc, BX, BY, lz_max, lz_fixed, &plan)) != WF_OK) return rc;
+      if (plan.ok) {
+        const int lz = plan.lz;
+        const size_t nslots = (size_t)plan.nitems * lz * CB;
+        // det J * w per cell and point, host copy in the caller's cell order and the engine's point order
+        std::vector<double> hd(ncells * nd);
+        if (desc->h_detJ) {
+          const std::vector<int32_t> qm = make_qmap(n);
+          for (size_t c = 0; c < ncells; ++c)
+            for (int q = 0; q < nd; ++q) hd[c * nd + q] = desc->h_detJ[c * nd + qm[q]];
+        } else {
+          Scratch<double> d_x, d_qp, d_qw, d_det;
+          Scratch<int32_t> d_gd;
+          const int use_fabs = (desc->flags & WF_FLAG_NO_FABS) ? 0 : 1;
+          if ((rc = dev_upload(&d_x.p, desc->h_xverts, (size_t)desc->nverts * 3, nullptr)) != WF_OK) return rc;
+          if ((rc = dev_upload(&d_gd.p, desc->h_geom_dofmap, ncells * 8, nullptr)) != WF_OK) return rc;
+          if ((rc = dev_upload(&d_qp.p, desc->h_qpts1, (size_t)n, nullptr)) != WF_OK) return rc;
+          if ((rc = dev_upload(&d_qw.p, desc->h_qwts1, (size_t)n, nullptr)) != WF_OK) return rc;
+          if ((rc = dev_alloc(&d_det.p, ncells * nd, nullptr)) != WF_OK) return rc;
+          if ((rc = launch_geometry_hex(P, desc->ncells, d_x.p, d_gd.p, d_qp.p, d_qw.p, use_fabs, 0, nullptr, nullptr, d_det.p,
+                                        nullptr)) != WF_OK)
+            return rc;
+          WF_HIP_CHECK(hipDeviceSynchronize());
+          WF_HIP_CHECK(hipMemcpy(hd.data(), d_det.p, hd.size() * sizeof(double), hipMemcpyDeviceToHost));
+        }
+        // blocked slot layout [item * lz + layer][k][t], t = slot_in_layer * n^2 + j n + i; empty slots zero
+        std::vector<double> blk(nslots * nd, 0.0);
+        for (size_t q = 0; q < nslots; ++q) {
+          const int32_t c = plan.slot_cell[q];
+          if (c < 0) continue;
+          const size_t sub = q / CB, sl = q % CB;
+          for (int k = 0; k < n; ++k)
+            std::memcpy(&blk[(sub * n + k) * NTq + sl * n * n], &hd[(size_t)c * nd + (size_t)k * n * n], (size_t)n * n * sizeof(double));
+        }
+        if ((rc = dev_upload(&op->d_detJ, blk.data(), blk.size(), &op->device_bytes)) != WF_OK) return rc;
+        if ((rc = dev_upload(&op->d_phi1, desc->h_phi1, (size_t)n * n, &op->device_bytes)) != WF_OK) return rc;
+        for (int q = 0; q < n * n; ++q) op->dm.v[q] = desc->h_phi1[q];
+        op->plan.nitems = plan.nitems;
+        op->plan.lz = lz;
+        op->plan.tile_size = plan.tile_size;
+        op->plan_patterns = plan.npatterns;
+        if ((rc = dev_upload(&op->plan.d_item_base, plan.item_base.data(), plan.item_base.size(), &op->device_bytes)) != WF_OK) return rc;
+        if ((rc = dev_upload(&op->plan.d_item_pattern, plan.item_pattern.data(), plan.item_pattern.size(), &op->device_bytes)) != WF_OK) return rc;
+        if ((rc = dev_upload(&op->plan.d_item_layers, plan.item_layers.data(), plan.item_layers.size(), &op->device_bytes)) != WF_OK) return rc;
+        if ((rc = dev_upload(&op->plan.d_pat_off, plan.pat_off.data(), plan.pat_off.size(), &op->device_bytes)) != WF_OK) return rc;
+        op->have_plan = 2;
+        op->nq1 = n;
+        op->nq = nd;
+        op->dense_square = 1;
+        WF_HIP_CHECK(hipDeviceSynchronize());
+        *out = op.release();
+        return WF_OK;
+      }
+    }
+  }
+
   // Internal cell order: cells are summed independently, so the operator may visit
   // them in any order.  Sorting by the smallest dof of each cell puts cells that
   // share dofs into the same workgroup batch whatever order the caller's mesh has
@@ -827,7 +902,7 @@ int wf_op_apply(wf_op* op, const double* d_x, double* d_y, void* stream)
   }
   switch (op->kind) {
     case WF_OP_STIFFNESS:
-      if (op->have_plan)
+      if (op->have_plan == 1)
         return launch_stiffness_march_idx(op->P, 0, op->plan, op->d_G6blk, op->d_D, op->dm, op->coeff, d_x, d_y, s);
       if (op->generic_unique)
         return launch_stiffness_generic_u(op->P, op->ncells, op->d_uoff, op->d_uniq, op->d_loc, op->d_G6blk, op->d_D,
@@ -841,6 +916,8 @@ int wf_op_apply(wf_op* op, const double* d_x, double* d_y, void* stream)
                                     d_y, s);
       return launch_mass_lumped((int64_t)op->ncells * op->nd, op->d_dofmap, op->d_detJ, d_x, d_y, s);
     case WF_OP_MASS_DENSE:
+      if (op->have_plan == 2)
+        return launch_mass_march_idx(op->P, op->plan, op->d_detJ, op->d_phi1, op->dm, d_x, d_y, s);
       if (op->dense_square && op->generic_unique)
         return launch_mass_dense_col(op->P, op->ncells, op->d_uoff, op->d_uniq, op->d_loc, op->d_phi1, op->d_detJ, d_x, d_y,
                                      s);

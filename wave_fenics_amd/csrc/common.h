@@ -86,6 +86,8 @@ struct MarchPlanDev {
 };
 int build_march_plan(int P, size_t ncells, const int32_t* tdm, int BX, int BY, int lz_max, int lz_fixed, MarchPlan* plan);
 size_t march_idx_lds_bytes(int P, int BX, int BY, int lz);
+int launch_mass_march_idx(int P, const MarchPlanDev& pd, const double* d_detJblk, const double* d_phi1, const DMat& pm,
+                          const double* d_x, double* d_y, hipStream_t s);
 int launch_stiffness_march_idx(int P, int variant, const MarchPlanDev& pd, const double* d_G6blk, const double* d_D,
                                const DMat& dm, double coeff, const double* d_x, double* d_y, hipStream_t s);
 // dense simplex operator (stiffness_dense.hip)

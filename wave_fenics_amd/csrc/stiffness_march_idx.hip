@@ -14,16 +14,97 @@
 // wait for the geometry prefetch issued before it).
 // HBM-bound; algorithmic bytes ncells (48 nq + 4 nd) + 16 ndofs; the index
 // table costs 4 P (P BX + 1)(P BY + 1) / (BX BY) bytes per cell when it is not L2-resident.
+//
+// OP selects the per-cell operator run on every layer:
+//   OP_STIFFNESS  stiffness_column<P> (stiffness_core.h), geometry = 6 doubles per point;
+//   OP_MASS       mass_column<P> below: y += Phi^T (detJ .* (Phi x)) with a square 1-D table
+//                 Phi = phi1 (x) phi1 (x) phi1 (MassOperator::apply, common/cuda/mass.hpp:76-84, the
+//                 DGEMM pair of demo/gpu_operator/main.cpp:144-160), geometry = 1 double per point.
+#include <type_traits>
+
 #include "stiffness_core.h"
 
 namespace wf {
 
-template <int P, int BX, int BY>
-__global__ __launch_bounds__(256, 2) void k_stiffness_march_idx(int lz, int tile_size, const int32_t* __restrict__ item_base,
+constexpr int OP_STIFFNESS = 0, OP_MASS = 1;
+
+// Column-thread core of the dense (sum-factorised) mass operator, the mass counterpart of
+// stiffness_column: thread (i, j) of a cell owns the column (i, j, *).  U: the cell inside the
+// layer's x tile (strides sk, sj); A, B: per-cell LDS scratch [n][n][n]; sP: LDS copy of
+// phi1[q][a]; pm: the same table as scalar operands; dj[k]: detJ * w at the points (i, j, k).
+// Three workgroup barriers inside; the caller provides one before A is written again.
+template <int P>
+__device__ __forceinline__ void mass_column(const double* __restrict__ U, int sk, int sj, double* __restrict__ A,
+                                            double* __restrict__ B, const double* __restrict__ sP, const DMat& pm,
+                                            const double (&dj)[P + 1], int i, int j, bool active, double (&out)[P + 1])
+{
+  constexpr int n = P + 1, n2 = n * n;
+  const int ji = j * n + i;
+  double v[n];
+  if (active) {   // forward x: A[k][j][qi = i] = sum_a phi[i][a] U[k][j][a]
+#pragma unroll
+    for (int k = 0; k < n; ++k) {
+      double s_ = 0.0;
+#pragma unroll
+      for (int a = 0; a < n; ++a) s_ += sP[i * n + a] * U[k * sk + j * sj + a];
+      A[k * n2 + ji] = s_;
+    }
+  }
+  __syncthreads();
+  if (active) {   // forward y (thread = (qi, qj)), forward z, detJ, backward z: registers
+    double vy[n], w[n];
+#pragma unroll
+    for (int k = 0; k < n; ++k) {
+      double s_ = 0.0;
+#pragma unroll
+      for (int a = 0; a < n; ++a) s_ += sP[j * n + a] * A[k * n2 + a * n + i];
+      vy[k] = s_;
+    }
+#pragma unroll
+    for (int q = 0; q < n; ++q) {
+      double s_ = 0.0;
+#pragma unroll
+      for (int k = 0; k < n; ++k) s_ += pm.v[q * n + k] * vy[k];
+      w[q] = s_ * dj[q];
+    }
+#pragma unroll
+    for (int k = 0; k < n; ++k) {
+      double s_ = 0.0;
+#pragma unroll
+      for (int q = 0; q < n; ++q) s_ += pm.v[q * n + k] * w[q];
+      B[k * n2 + ji] = s_;   // B1[k][qj][qi]
+    }
+  }
+  __syncthreads();
+  if (active) {   // backward y: A[k][j][qi = i] = sum_qj phi[qj][j] B1[k][qj][i]
+#pragma unroll
+    for (int k = 0; k < n; ++k) {
+      double s_ = 0.0;
+#pragma unroll
+      for (int q = 0; q < n; ++q) s_ += sP[q * n + j] * B[k * n2 + q * n + i];
+      v[k] = s_;
+    }
+#pragma unroll
+    for (int k = 0; k < n; ++k) A[k * n2 + ji] = v[k];
+  }
+  __syncthreads();
+  if (active) {   // backward x: out[k] = sum_qi phi[qi][i] A[k][j][qi]
+#pragma unroll
+    for (int k = 0; k < n; ++k) {
+      double s_ = 0.0;
+#pragma unroll
+      for (int q = 0; q < n; ++q) s_ += sP[q * n + i] * A[k * n2 + j * n + q];
+      out[k] = s_;
+    }
+  }
+}
+
+template <int OP, int P, int BX, int BY>
+__global__ __launch_bounds__(256, 2) void k_march_idx(int lz, int tile_size, const int32_t* __restrict__ item_base,
                                                                 const int32_t* __restrict__ item_pattern,
                                                                 const int32_t* __restrict__ item_layers,
                                                                 const int32_t* __restrict__ pat_off,
-                                                                const double2* __restrict__ G6blk,
+                                                                const void* __restrict__ geom,
                                                                 const double* __restrict__ dD, DMat dm, double coeff,
                                                                 const double* __restrict__ x, double* __restrict__ y)
 {
@@ -51,13 +132,22 @@ __global__ __launch_bounds__(256, 2) void k_stiffness_march_idx(int lz, int tile
   const int cl = t / n2, ji = t % n2, j = ji / n, i = ji % n;
   const int lx = cl % BX, ly = cl / BX;
 
-  double2 gcur[n][3], gnext[n][3];
-  auto load_g = [&](double2 (&g)[n][3], int l) {
-    const double2* gp = G6blk + ((item * lz + l) * n * 3) * (size_t)NT + t;
+  // geometry registers: stiffness 3 x double2 per point (G upper triangle), mass 1 double (detJ w)
+  constexpr int GW = OP == OP_STIFFNESS ? 3 : 1;
+  using GT = typename std::conditional<OP == OP_STIFFNESS, double2, double>::type;
+  GT gcur[n][GW], gnext[n][GW];
+  auto load_g = [&](GT (&g)[n][GW], int l) {
+    if constexpr (OP == OP_STIFFNESS) {
+      const double2* gp = static_cast<const double2*>(geom) + ((item * lz + l) * n * 3) * (size_t)NT + t;
 #pragma unroll
-    for (int k = 0; k < n; ++k)
+      for (int k = 0; k < n; ++k)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) g[k][p] = load_stream(gp + (size_t)(k * 3 + p) * NT);
+        for (int p = 0; p < 3; ++p) g[k][p] = load_stream(gp + (size_t)(k * 3 + p) * NT);
+    } else {
+      const double* gp = static_cast<const double*>(geom) + ((item * lz + l) * n) * (size_t)NT + t;
+#pragma unroll
+      for (int k = 0; k < n; ++k) g[k][0] = __builtin_nontemporal_load(gp + (size_t)k * NT);
+    }
   };
   // index table first (L2-resident for regular numberings), then the first layer's geometry and
   // x planes together: one HBM latency in the prologue, not two (loads retire in order)
@@ -96,7 +186,14 @@ __global__ __launch_bounds__(256, 2) void k_stiffness_march_idx(int lz, int tile
 
     // (b) element kernels of the layer
     double out[n];
-    stiffness_column<P>(Uc, TP, TX, Fr + cl * nd, Fs + cl * nd, sD, dm, gcur, coeff, i, j, active, out);
+    if constexpr (OP == OP_STIFFNESS) {
+      stiffness_column<P>(Uc, TP, TX, Fr + cl * nd, Fs + cl * nd, sD, dm, gcur, coeff, i, j, active, out);
+    } else {
+      double djk[n];
+#pragma unroll
+      for (int k = 0; k < n; ++k) djk[k] = gcur[k][0];
+      mass_column<P>(Uc, TP, TX, Fr + cl * nd, Fs + cl * nd, sD, dm, djk, i, j, active, out);
+    }
     double xcp[NCP];
 #pragma unroll
     for (int m = 0; m < NCP; ++m) {
@@ -147,7 +244,7 @@ __global__ __launch_bounds__(256, 2) void k_stiffness_march_idx(int lz, int tile
 #pragma unroll
       for (int k = 0; k < n; ++k)
 #pragma unroll
-        for (int p = 0; p < 3; ++p) gcur[k][p] = gnext[k][p];
+        for (int p = 0; p < GW; ++p) gcur[k][p] = gnext[k][p];
     }
     __syncthreads();
   }
@@ -176,7 +273,7 @@ __global__ __launch_bounds__(256, 2) void k_stiffness_march_idx(int lz, int tile
   }
 }
 
-template <int P, int BX, int BY>
+template <int OP, int P, int BX, int BY>
 static int launch_t(const MarchPlanDev& pd, const double* d_G6blk, const double* d_D, const DMat& dm, double coeff,
                     const double* d_x, double* d_y, hipStream_t s)
 {
@@ -184,13 +281,13 @@ static int launch_t(const MarchPlanDev& pd, const double* d_G6blk, const double*
   const size_t dyn = (size_t)pd.tile_size * sizeof(int32_t);
   static size_t dyn_set = 0;   // per instantiation: static + dynamic LDS may exceed the 64 KB default limit
   if (dyn > dyn_set) {
-    WF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stiffness_march_idx<P, BX, BY>),
+    WF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_march_idx<OP, P, BX, BY>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
     dyn_set = dyn;
   }
-  hipLaunchKernelGGL((k_stiffness_march_idx<P, BX, BY>), dim3((unsigned)pd.nitems), dim3(256), dyn, s, pd.lz, pd.tile_size,
+  hipLaunchKernelGGL((k_march_idx<OP, P, BX, BY>), dim3((unsigned)pd.nitems), dim3(256), dyn, s, pd.lz, pd.tile_size,
                      pd.d_item_base, pd.d_item_pattern, pd.d_item_layers, pd.d_pat_off,
-                     reinterpret_cast<const double2*>(d_G6blk), d_D, dm, coeff, d_x, d_y);
+                     static_cast<const void*>(d_G6blk), d_D, dm, coeff, d_x, d_y);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     set_error(std::string("stiffness_march_idx launch failed: ") + hipGetErrorString(e));
@@ -211,12 +308,29 @@ int launch_stiffness_march_idx(int P, int variant, const MarchPlanDev& pd, const
 {
   (void)variant;
   switch (P) {   // the cross-sections with BX * BY == floor(256 / n^2) cells (geometry batch layout)
-    case 1: return launch_t<1, 8, 8>(pd, d_G6blk, d_D, dm, coeff, d_x, d_y, s);
-    case 2: return launch_t<2, 7, 4>(pd, d_G6blk, d_D, dm, coeff, d_x, d_y, s);
-    case 3: return launch_t<3, 4, 4>(pd, d_G6blk, d_D, dm, coeff, d_x, d_y, s);
-    case 4: return launch_t<4, 5, 2>(pd, d_G6blk, d_D, dm, coeff, d_x, d_y, s);
+    case 1: return launch_t<OP_STIFFNESS, 1, 8, 8>(pd, d_G6blk, d_D, dm, coeff, d_x, d_y, s);
+    case 2: return launch_t<OP_STIFFNESS, 2, 7, 4>(pd, d_G6blk, d_D, dm, coeff, d_x, d_y, s);
+    case 3: return launch_t<OP_STIFFNESS, 3, 4, 4>(pd, d_G6blk, d_D, dm, coeff, d_x, d_y, s);
+    case 4: return launch_t<OP_STIFFNESS, 4, 5, 2>(pd, d_G6blk, d_D, dm, coeff, d_x, d_y, s);
   }
   set_error("stiffness_march_idx: compiled for degrees 1..4");
+  return WF_ERR_UNSUPPORTED;
+}
+
+// dense mass with a square 1-D table: d_detJblk [item][layer][k][CB n^2] (detJ w at the points), d_phi1 / pm = phi1[q][a]
+int launch_mass_march_idx(int P, const MarchPlanDev& pd, const double* d_detJblk, const double* d_phi1, const DMat& pm,
+                          const double* d_x, double* d_y, hipStream_t s)
+{
+  switch (P) {
+    case 1: return launch_t<OP_MASS, 1, 8, 8>(pd, d_detJblk, d_phi1, pm, 0.0, d_x, d_y, s);
+    case 2: return launch_t<OP_MASS, 2, 7, 4>(pd, d_detJblk, d_phi1, pm, 0.0, d_x, d_y, s);
+    case 3: return launch_t<OP_MASS, 3, 4, 4>(pd, d_detJblk, d_phi1, pm, 0.0, d_x, d_y, s);
+    case 4: return launch_t<OP_MASS, 4, 5, 2>(pd, d_detJblk, d_phi1, pm, 0.0, d_x, d_y, s);
+    case 5: return launch_t<OP_MASS, 5, 7, 1>(pd, d_detJblk, d_phi1, pm, 0.0, d_x, d_y, s);
+    case 6: return launch_t<OP_MASS, 6, 5, 1>(pd, d_detJblk, d_phi1, pm, 0.0, d_x, d_y, s);
+    case 7: return launch_t<OP_MASS, 7, 2, 2>(pd, d_detJblk, d_phi1, pm, 0.0, d_x, d_y, s);
+  }
+  set_error("mass_march_idx: degree must be 1..7");
   return WF_ERR_UNSUPPORTED;
 }
 
