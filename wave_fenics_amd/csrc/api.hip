@@ -375,6 +375,9 @@ int wf_op_create(const wf_op_desc* desc, wf_op** out)
   {
     const char* gk = std::getenv("WF_GENERIC");
     const bool legacy = gk && (std::strcmp(gk, "flat") == 0 || std::strcmp(gk, "u") == 0);
+    // P >= 5: two geometry register sets do not fit 256 VGPRs; a single set refilled level by level
+    // ("rolling") compiles to 256 VGPRs + spills and measured slower than the batch kernel
+    // (10.2 M dofs: P5 0.288 vs 0.272 ms, P6 0.367 vs 0.261 ms, P7 0.526 vs 0.293 ms) -- batch kernel there
     if (desc->kind == WF_OP_STIFFNESS && !legacy && P <= 4 && ncells > 0) {
       WF_REQUIRE(desc->h_G || have_mesh, "wf_op_create: stiffness needs h_G or the mesh (h_xverts, h_geom_dofmap)");
       // tensor-ordered dofmap in the caller's cell order (permute.hpp:10-27)

@@ -41,7 +41,9 @@ __device__ __forceinline__ double clamp101d(double v)
 }
 
 // QT = ceil(nq/16), KT = ceil(nd/4), DT = ceil(nd/16); KP = row pitch of T in LDS.
-template <int QT, int KT, int DT, int NW>
+// NU: unique dofs of a batch per thread (numax <= NU * 64 NW), a compile-time bound for the
+// register-staged gather of the NEXT batch.
+template <int QT, int KT, int DT, int NW, int NU>
 __global__ __launch_bounds__(64 * NW) void k_stiffness_dense(int nd, int nq, int nbatch, int numax,
                                                          const double* __restrict__ Tg,      // [3*16*QT][KP] padded table
                                                          const double* __restrict__ wq,      // [16*QT] weights (0 beyond nq)
@@ -49,6 +51,7 @@ __global__ __launch_bounds__(64 * NW) void k_stiffness_dense(int nd, int nq, int
                                                          const uint16_t* __restrict__ locT,  // [nbatch][4*KT][16*NW]
                                                          const int32_t* __restrict__ uoff,   // [nbatch+1]
                                                          const int32_t* __restrict__ uniq,   // unique dofs of all batches
+                                                         const uint8_t* __restrict__ clampb, // [nbatch] 1: some w_q C_c of the batch lies in a clamp window
                                                          double coeff, int do_clamp, const double* __restrict__ x,
                                                          double* __restrict__ y, int ablate)
 {
@@ -56,35 +59,75 @@ __global__ __launch_bounds__(64 * NW) void k_stiffness_dense(int nd, int nq, int
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* T = smem;                 // [3*NQP][KP]
   double* sw = T + 3 * NQP * KP;    // [NQP]
-  double* Xu = sw + NQP;            // [numax]  unique x values, later the unique y sums
+  double* Xu = sw + NQP;            // [numax]  x at the unique dofs of the batch
+  double* Yu = Xu + numax;          // [numax]  sum of the cell results per unique dof
 
   (void)nq;
-  (void)numax;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int lc = lane & 15, lg = lane >> 4;
   for (int p = t; p < 3 * NQP * KP; p += NT) T[p] = Tg[p];
   for (int p = t; p < NQP; p += NT) sw[p] = wq[p];
 
-  for (int batch = blockIdx.x; batch < nbatch; batch += gridDim.x) {
-    const int u0 = uoff[batch], nu = uoff[batch + 1] - u0;
-    __syncthreads();   // previous batch's scatter has read Xu
-    for (int u = t; u < nu; u += NT) Xu[u] = (ablate & 4) ? 1.0 + u : x[uniq[u0 + u]];
-    // per-lane local indices: d = 4*ks + lg of cell (wave*16 + lc)
-    uint16_t loc[KT];
+  // Software pipeline over the batches of this (persistent) workgroup: while batch b is in its
+  // MFMA section, the gather of batch b + G is in flight in registers (x values xr, local
+  // indices and geometry) and the unique-dof list of batch b + 2G is being fetched (uq), so the
+  // only memory latency left on the critical path is the scatter's.  Inside the MFMA section no
+  // global load is consumed (loads retire in order).
+  const int G = gridDim.x;
+  auto load_uq = [&](int32_t (&uq)[NU], int b) {
+    const int u0 = b < nbatch ? uoff[b] : 0, nu = b < nbatch ? uoff[b + 1] - u0 : 0;
 #pragma unroll
-    for (int ks = 0; ks < KT; ++ks) loc[ks] = locT[((size_t)batch * 4 * KT + 4 * ks + lg) * NCB + wave * 16 + lc];
-    double C[6];
-    {
-      const double* cp = Cg + ((size_t)batch * NCB + wave * 16 + lc) * 6;
-#pragma unroll
-      for (int e = 0; e < 6; ++e) C[e] = cp[e];
+    for (int m = 0; m < NU; ++m) {
+      const int u = t + NT * m;
+      uq[m] = u < nu ? uniq[u0 + u] : -1;
     }
-    __syncthreads();
+  };
+  auto load_x = [&](double (&xr)[NU], const int32_t (&uq)[NU]) {
+#pragma unroll
+    for (int m = 0; m < NU; ++m) xr[m] = uq[m] >= 0 ? ((ablate & 4) ? 1.0 + m : x[uq[m]]) : 0.0;
+  };
+  auto load_cell = [&](uint16_t (&loc)[KT], double (&C)[6], int b) {
+    if (b >= nbatch) return;
+#pragma unroll
+    for (int ks = 0; ks < KT; ++ks) loc[ks] = locT[((size_t)b * 4 * KT + 4 * ks + lg) * NCB + wave * 16 + lc];
+    const double* cp = Cg + ((size_t)b * NCB + wave * 16 + lc) * 6;
+#pragma unroll
+    for (int e = 0; e < 6; ++e) C[e] = cp[e];
+  };
+  int32_t uq_cur[NU], uq_nxt[NU];     // unique dofs (this thread's share) of the batch being computed / of the next one
+  double xr[NU];
+  uint16_t loc[KT], locn[KT];
+  double C[6], Cn[6];
+  // prologue: first batch straight into LDS, indices of the second
+  load_uq(uq_cur, blockIdx.x);
+  load_x(xr, uq_cur);
+  load_cell(loc, C, blockIdx.x);
+  load_uq(uq_nxt, blockIdx.x + G);
+#pragma unroll
+  for (int m = 0; m < NU; ++m) {
+    const int u = t + NT * m;
+    if (u < numax) {
+      Xu[u] = xr[m];
+      Yu[u] = 0.0;
+    }
+  }
+
+  for (int batch = blockIdx.x; batch < nbatch; batch += G) {
+    // the -1/0/1 clamp of G (precomputation.hpp:105-107) is the identity unless a product w_q C_c
+    // falls into one of its windows; the host marks the batches where that happens (same
+    // double-precision products), every other batch skips ~200 VALU instructions per slab
+    const bool clamp_here = do_clamp && clampb[batch];
+    __syncthreads();   // Xu holds this batch's x values, Yu is zero
 
     // B operands of the first product: this lane's dof values, one per k-step
     double ub[KT];
 #pragma unroll
     for (int ks = 0; ks < KT; ++ks) ub[ks] = (4 * ks + lg) < nd ? Xu[loc[ks]] : 0.0;
+    // gather of the next batch (registers) and index list of the one after it
+    int32_t uq_nn[NU];
+    load_x(xr, uq_nxt);
+    load_cell(locn, Cn, batch + G);
+    load_uq(uq_nn, batch + 2 * G);
 
     double4_t Y[DT];
 #pragma unroll
@@ -131,7 +174,7 @@ __global__ __launch_bounds__(64 * NW) void k_stiffness_dense(int nd, int nq, int
         const int q = 16 * qt + lg + 4 * r;
         const double w = sw[q];
         double g00 = w * C[0], g01 = w * C[1], g02 = w * C[2], g11 = w * C[3], g12 = w * C[4], g22 = w * C[5];
-        if (do_clamp) {   // precomputation.hpp:105-107
+        if (clamp_here) {   // precomputation.hpp:105-107
           g00 = clamp101d(g00); g01 = clamp101d(g01); g02 = clamp101d(g02);
           g11 = clamp101d(g11); g12 = clamp101d(g12); g22 = clamp101d(g22);
         }
@@ -159,24 +202,35 @@ __global__ __launch_bounds__(64 * NW) void k_stiffness_dense(int nd, int nq, int
       }
     }
     // ---- per-batch accumulation over unique dofs, then one atomic per unique dof
-    __syncthreads();   // every wave has finished reading Xu
-    for (int u = t; u < nu; u += NT) Xu[u] = 0.0;
-    __syncthreads();
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int ks = 4 * dt + r;   // d = 16 dt + lg + 4 r = 4 ks + lg
-        if (ks < KT && 4 * ks + lg < nd) atomicAdd(&Xu[loc[ks < KT ? ks : 0]], Y[dt][r]);
+        if (ks < KT && 4 * ks + lg < nd) atomicAdd(&Yu[loc[ks < KT ? ks : 0]], Y[dt][r]);
       }
-    __syncthreads();
-    for (int u = t; u < nu; u += NT) {
-      if (ablate & 1) {
-        if (Xu[u] == 1.2345e300) y[uniq[u0 + u]] = Xu[u];
-      } else {
-        unsafeAtomicAdd(&y[uniq[u0 + u]], Xu[u]);
+    __syncthreads();   // Yu complete; every wave has taken its operands out of Xu
+#pragma unroll
+    for (int m = 0; m < NU; ++m) {
+      const int u = t + NT * m;
+      if (uq_cur[m] >= 0) {
+        if (ablate & 1) {
+          if (Yu[u] == 1.2345e300) y[uq_cur[m]] = Yu[u];
+        } else {
+          unsafeAtomicAdd(&y[uq_cur[m]], Yu[u]);
+        }
       }
+      if (u < numax) {   // same thread, same entries: next batch's x values in, sums back to zero
+        Xu[u] = xr[m];
+        Yu[u] = 0.0;
+      }
+      uq_cur[m] = uq_nxt[m];
+      uq_nxt[m] = uq_nn[m];
     }
+#pragma unroll
+    for (int ks = 0; ks < KT; ++ks) loc[ks] = locn[ks];
+#pragma unroll
+    for (int e = 0; e < 6; ++e) C[e] = Cn[e];
   }
 }
 
@@ -188,6 +242,7 @@ struct DenseOpData {
   uint16_t* d_locT = nullptr;
   int32_t* d_uoff = nullptr;
   int32_t* d_uniq = nullptr;
+  uint8_t* d_clampb = nullptr;
   size_t bytes = 0;
 };
 
@@ -200,6 +255,7 @@ void dense_free(DenseOpData* d)
   (void)hipFree(d->d_locT);
   (void)hipFree(d->d_uoff);
   (void)hipFree(d->d_uniq);
+  (void)hipFree(d->d_clampb);
   delete d;
 }
 
@@ -226,7 +282,7 @@ int dense_setup(int nd, int nq, int ncells, int ndofs, const int32_t* dofmap, co
   d->KT = (nd + 3) / 4;
   d->DT = (nd + 15) / 16;
   d->nw = 4;
-  if (const char* e = std::getenv("WF_DENSE_WAVES")) d->nw = (std::atoi(e) == 8) ? 8 : 4;   // tuning hook
+
   const int NCB = 16 * d->nw;
   const int NQP = 16 * d->QT, KP = 4 * d->KT + 1;
   std::vector<double> T((size_t)3 * NQP * KP, 0.0), w(NQP, 0.0);
@@ -291,6 +347,17 @@ int dense_setup(int nd, int nq, int ncells, int ndofs, const int32_t* dofmap, co
   }
   d->numax = std::max(numax, 1);
   (void)ndofs;
+  // batches in which the clamp is not the identity
+  std::vector<uint8_t> clampb(nbatch, 0);
+  for (int c = 0; c < ncells; ++c) {
+    bool hit = false;
+    for (int q = 0; q < nq && !hit; ++q)
+      for (int e = 0; e < 6 && !hit; ++e) {
+        const double a = std::fabs(weights[q] * C[(size_t)c * 6 + e]);
+        hit = (a > 0.0 && a <= 1e-8) || (a != 1.0 && std::fabs(a - 1.0) <= 1e-8 + 1e-5);
+      }
+    if (hit) clampb[c / NCB] = 1;
+  }
   int rc;
   if ((rc = up(&d->d_T, T, &d->bytes)) != WF_OK) return rc;
   if ((rc = up(&d->d_w, w, &d->bytes)) != WF_OK) return rc;
@@ -298,29 +365,30 @@ int dense_setup(int nd, int nq, int ncells, int ndofs, const int32_t* dofmap, co
   if ((rc = up(&d->d_locT, locT, &d->bytes)) != WF_OK) return rc;
   if ((rc = up(&d->d_uoff, uoff, &d->bytes)) != WF_OK) return rc;
   if ((rc = up(&d->d_uniq, uniq, &d->bytes)) != WF_OK) return rc;
+  if ((rc = up(&d->d_clampb, clampb, &d->bytes)) != WF_OK) return rc;
   *out = d.release();
   return WF_OK;
 }
 
 size_t dense_bytes(const DenseOpData* d) { return d ? d->bytes : 0; }
 
-template <int QT, int KT, int DT, int NW>
+template <int QT, int KT, int DT, int NW, int NU>
 static int launch_dense_t(const DenseOpData* d, double coeff, int do_clamp, const double* d_x, double* d_y,
                           hipStream_t s)
 {
   constexpr int NQP = 16 * QT, KP = 4 * KT + 1;
-  const size_t lds = ((size_t)3 * NQP * KP + NQP + d->numax) * sizeof(double);
+  const size_t lds = ((size_t)3 * NQP * KP + NQP + 2 * d->numax) * sizeof(double);
   if (lds > 160 * 1024) {
     set_error("stiffness_dense: tables do not fit LDS");
     return WF_ERR_UNSUPPORTED;
   }
-  auto kern = k_stiffness_dense<QT, KT, DT, NW>;
+  auto kern = k_stiffness_dense<QT, KT, DT, NW, NU>;
   if (lds > 64 * 1024)
     WF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds));
   const unsigned nb = (unsigned)std::min(d->nbatch, 256 * 2);   // persistent: the table is staged into LDS once per workgroup
   hipLaunchKernelGGL(kern, dim3(nb), dim3(64 * NW), lds, s, d->nd, d->nq, d->nbatch, d->numax, d->d_T, d->d_w, d->d_C,
-                     d->d_locT, d->d_uoff, d->d_uniq, coeff, do_clamp, d_x, d_y,
+                     d->d_locT, d->d_uoff, d->d_uniq, d->d_clampb, coeff, do_clamp, d_x, d_y,
                      std::getenv("WF_ABLATE") ? std::atoi(std::getenv("WF_ABLATE")) : 0);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
@@ -330,10 +398,11 @@ static int launch_dense_t(const DenseOpData* d, double coeff, int do_clamp, cons
   return WF_OK;
 }
 
+// NU = 5 covers the unique dofs of 64 well-numbered P4 cells (1154 on the Kuhn box); 9 is the worst case 64 * 35
 #define WF_DENSE_CASE(Q, K, D)                                                                                   \
   if (d->QT == Q && d->KT == K && d->DT == D)                                                                    \
-    return d->nw == 8 ? launch_dense_t<Q, K, D, 8>(d, coeff, do_clamp, d_x, d_y, s)                              \
-                      : launch_dense_t<Q, K, D, 4>(d, coeff, do_clamp, d_x, d_y, s);
+    return d->numax <= 5 * 256 ? launch_dense_t<Q, K, D, 4, 5>(d, coeff, do_clamp, d_x, d_y, s)                   \
+                               : launch_dense_t<Q, K, D, 4, 9>(d, coeff, do_clamp, d_x, d_y, s);
 
 // Compiled shapes: Lagrange P1..P4 on the tetrahedron with the m = p Gauss-Jacobi
 // rule (nd, nq) = (4,1) (10,8) (20,27) (35,64), plus P4 with the m = 3 rule.
