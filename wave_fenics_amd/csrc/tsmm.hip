@@ -59,25 +59,36 @@ __global__ __launch_bounds__(512) void k_tsmm(int64_t ncells, int K, int N, int 
   __syncthreads();
   const double* bp = sphi + lg * NP + lc;   // B operand of k-step ks, tile nt: bp[(4 ks) NP + 16 nt]
   const int64_t ntiles = (ncells + 15) / 16;
-  for (int64_t tile = (int64_t)blockIdx.x * 8 + wave; tile < ntiles; tile += (int64_t)gridDim.x * 8) {
+  const int64_t tstride = (int64_t)gridDim.x * 8;
+  // A operands stream from HBM as a flat sequence of (cell tile, k chunk) pairs; the loads of the
+  // pair two steps ahead are always in flight, ACROSS tile boundaries, so a wave never starts a
+  // tile by waiting for its first operands.
+  auto load_a = [&](double (&a)[CH], int64_t tile, int ch) {
+    tile += (ch / nch) * tstride;
+    ch %= nch;
+    const int64_t c = tile * 16 + lc;
+    const bool ok = tile < ntiles && c < ncells;
+#pragma unroll
+    for (int q = 0; q < CH; ++q) {
+      const int k = 4 * (ch * CH + q) + lg;
+      a[q] = (ok && k < K) ? (LAYOUT == 0 ? in[c * K + k] : in[(int64_t)k * ncells + c]) : 0.0;
+    }
+  };
+  double a_cur[CH], a_nxt[CH], a_nn[CH], pb[NT], pn[NT];
+  {
+    const int64_t first = (int64_t)blockIdx.x * 8 + wave;
+    load_a(a_cur, first, 0);
+    load_a(a_nxt, first, 1);
+  }
+  for (int64_t tile = (int64_t)blockIdx.x * 8 + wave; tile < ntiles; tile += tstride) {
     const int64_t c0 = tile * 16;
     double4_t acc[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[nt] = double4_t{0.0, 0.0, 0.0, 0.0};
-    const int64_t c = c0 + lc;
-    auto load_a = [&](double (&a)[CH], int ch) {
-#pragma unroll
-      for (int q = 0; q < CH; ++q) {
-        const int k = 4 * (ch * CH + q) + lg;
-        a[q] = (k < K && c < ncells) ? (LAYOUT == 0 ? in[c * K + k] : in[(int64_t)k * ncells + c]) : 0.0;
-      }
-    };
-    double a_cur[CH], a_nxt[CH], pb[NT], pn[NT];
-    load_a(a_cur, 0);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) pb[nt] = bp[16 * nt];
     for (int ch = 0; ch < nch; ++ch) {
-      if (ch + 1 < nch) load_a(a_nxt, ch + 1);
+      load_a(a_nn, tile, ch + 2);
 #pragma unroll
       for (int q = 0; q < CH; ++q) {
         // next k-step's B operands (the row after the table's last one is never read: ks + 1 < rows / 4)
@@ -97,7 +108,10 @@ __global__ __launch_bounds__(512) void k_tsmm(int64_t ncells, int K, int N, int 
         for (int nt = 0; nt < NT; ++nt) pb[nt] = pn[nt];
       }
 #pragma unroll
-      for (int q = 0; q < CH; ++q) a_cur[q] = a_nxt[q];
+      for (int q = 0; q < CH; ++q) {
+        a_cur[q] = a_nxt[q];
+        a_nxt[q] = a_nn[q];
+      }
     }
     // D layout: row = lg + 4 r, col = lc
 #pragma unroll
