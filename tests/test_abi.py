@@ -98,6 +98,6 @@ def test_cxx_host_drivers_build(wlib, tmp_path):
     import subprocess
     out = str(tmp_path / "bin")
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "examples"), f"OUT={out}", "CXXFLAGS=-O1 -std=c++17 -Wall -Werror"])
-    for exe in ("planar3d", "operator_demo", "tsmm_demo", "scatter_demo"):
+    for exe in ("planar3d", "operator_demo", "tsmm_demo", "scatter_demo", "cg_demo"):
         r = subprocess.run([os.path.join(out, exe), "--bogus"], capture_output=True, text=True, timeout=60)
         assert r.returncode == 2 and "usage" in r.stderr

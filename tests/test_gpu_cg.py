@@ -3,6 +3,8 @@ against a dense numpy solve of the oracle's mass matrix, against a numpy CG for 
 iteration count, through the Python callback, on a periodic partition with the
 native RCCL updater (halo + all-reduce inside the solver), and residual /
 iteration-count known answers at larger size."""
+import os
+
 import numpy as np
 import pytest
 
@@ -147,3 +149,21 @@ def test_cg_lumped_mass_cfg_size(gpu):
     its, res = la.cg(x, b, M, kmax=100, rtol=1e-10)
     assert its <= 2 * ndistinct and res < 1e-10, (its, ndistinct)     # exact arithmetic: its <= ndistinct
     assert float(((x - b / m).abs() / (b / m).abs()).max()) <= 1e-8
+
+
+@pytest.mark.parametrize("opname,degree", [("lumped", 2), ("dense", 2), ("dense", 4)])
+def test_cxx_cg_demo(gpu, tmp_path, opname, degree):
+    """examples/cg_demo.cpp = demo/gpu_cg/main.cpp (BP1: mass-operator CG, f = x0 + 4, kmax 50,
+    rtol 1e-4): the C++ host side converges within kmax and reproduces f."""
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "bin")
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "examples"), f"OUT={out}", "CXXFLAGS=-O1 -std=c++17"])
+    r = subprocess.run([os.path.join(out, "cg_demo"), "--size", "8", "--degree", str(degree), "--op", opname],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    its = int(re.search(r"its = (\d+)", r.stdout).group(1))
+    err = float(re.search(r"max \|u - f\|: (\S+)", r.stdout).group(1))
+    assert 1 <= its <= 50
+    assert err < (1e-10 if opname == "lumped" else 5e-3), r.stdout
