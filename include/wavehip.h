@@ -242,7 +242,9 @@ int wf_transform1(int32_t N, const double* d_in, const double* d_detJ, double* d
  * products of demo/gpu_operator/main.cpp:149-155 (fp64 MFMA 16x16x4).
  * layout 0: in[cell*K + k], out[cell*N + n]   (cell-major, demo/gpu_operator)
  * layout 1: in[k*ncells + cell], out[n*ncells + cell]   (the column-major arrays
- *           of demo/gpu_tsmm with lda = ldc = ncells). */
+ *           of demo/gpu_tsmm with lda = ldc = ncells).
+ * Any K, N > 0: columns run in passes of 128, table rows in ranges of <= 128 that
+ * accumulate onto out (so out is read as well as written when K > 128). */
 int wf_tsmm(int layout, int64_t ncells, int K, int N, const double* d_in, const double* d_phi, double* d_out,
             void* stream);
 

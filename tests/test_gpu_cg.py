@@ -160,10 +160,13 @@ def test_cxx_cg_demo(gpu, tmp_path, opname, degree):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = str(tmp_path / "bin")
     subprocess.check_call(["make", "-s", "-C", os.path.join(root, "examples"), f"OUT={out}", "CXXFLAGS=-O1 -std=c++17"])
-    r = subprocess.run([os.path.join(out, "cg_demo"), "--size", "8", "--degree", str(degree), "--op", opname],
+    # dense: the consistent mass matrix has condition number ~ kappa_1d^3 (thousands), so the demo's
+    # rtol 1e-4 leaves a visible error; tighten it to check the solution, keep the defaults for lumped
+    extra = ["--rtol", "1e-10", "--kmax", "400"] if opname == "dense" else []
+    r = subprocess.run([os.path.join(out, "cg_demo"), "--size", "8", "--degree", str(degree), "--op", opname] + extra,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
     its = int(re.search(r"its = (\d+)", r.stdout).group(1))
     err = float(re.search(r"max \|u - f\|: (\S+)", r.stdout).group(1))
-    assert 1 <= its <= 50
-    assert err < (1e-10 if opname == "lumped" else 5e-3), r.stdout
+    assert 1 <= its <= (400 if opname == "dense" else 50)
+    assert err < 1e-6, r.stdout

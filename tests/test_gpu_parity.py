@@ -792,11 +792,13 @@ def test_generic_ops_random_cell_order(gpu, oracle):
 
 
 @pytest.mark.parametrize("ncells,K,N", [(1000, 125, 125), (37, 27, 27), (513, 64, 64), (100, 8, 8), (77, 35, 192),
-                                        (50, 125, 216), (16, 3, 5)])
+                                        (50, 125, 216), (16, 3, 5), (300, 216, 216), (130, 343, 343), (40, 512, 512),
+                                        (64, 129, 40), (33, 216, 125)])
 def test_tsmm_vs_numpy(gpu, ncells, K, N):
     """wf_tsmm in both array layouts (demo/gpu_operator cell-major, demo/gpu_tsmm
     column-major with lda = ncells) against a float64 numpy product: k-ordered
-    fma chains, tolerance 1e-13 of the row magnitude."""
+    fma chains, tolerance 1e-13 of the row magnitude.  K > 128 (the P5..P7 tables of
+    demo/gpu_operator: 216, 343, 512) runs as row ranges accumulating onto out."""
     import torch
     import wave_fenics_amd as w
     rng = np.random.default_rng(ncells + K)

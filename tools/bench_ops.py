@@ -71,7 +71,7 @@ def bench_tet(dev):
 
 def bench_tsmm(dev):
     # demo/gpu_tsmm/main.cpp: ndofs = 125, ncells = 100000, two products, GFLOPs = 4*ncells*nd^2/t
-    for ncells, nd in ((100000, 125), (1000000, 125), (1000000, 64), (2000000, 27)):
+    for ncells, nd in ((100000, 125), (1000000, 125), (1000000, 64), (2000000, 27), (300000, 216), (200000, 343)):
         xe = torch.rand(ncells * nd, dtype=torch.float64, device=dev)
         xq = torch.zeros_like(xe)
         ue = torch.zeros_like(xe)

@@ -29,10 +29,15 @@ constexpr int kTsmmChunk = 8;
 // NT: accumulator tiles (16 columns each) per wave.  (Splitting a cell tile's columns over
 // several waves for small problems was measured at the reference shape 100 000 x 125:
 // no gain -- 0.225 / 0.219 / 0.249 ms per pair of products with 1 / 2 / 4 parts.)
-template <int NT, int LAYOUT>
-__global__ __launch_bounds__(512) void k_tsmm(int64_t ncells, int K, int N, int n0, const double* __restrict__ in,
-                                              const double* __restrict__ phi, double* __restrict__ out)
+template <int NT, int LAYOUT, bool ACC>
+__global__ __launch_bounds__(512) void k_tsmm(int64_t ncells, int Kfull, int N, int n0, int k0, int K,
+                                              const double* __restrict__ in, const double* __restrict__ phi,
+                                              double* __restrict__ out)
 {
+  // This launch covers table rows [k0, k0 + K) and columns [n0, n0 + 16 NT); with ACC the
+  // accumulators start from out (the earlier row ranges of a K > 128 product).  ACC is a template
+  // parameter: as a run-time branch the conditional loads made the compiler's vmcnt bookkeeping
+  // conservative in the main loop and cost 15 % on the plain K <= 128 product.
   extern __shared__ __attribute__((aligned(16))) double sphi[];   // [4 * CH * nch][NP] (zero padded)
   // Row stride of the table in LDS: a wave's B-operand read (ds_read_b64) is served in two 32-lane
   // halves, each holding two k rows of 16 consecutive doubles; the halves are conflict-free when the
@@ -51,7 +56,7 @@ __global__ __launch_bounds__(512) void k_tsmm(int64_t ncells, int K, int N, int 
 #pragma unroll
     for (int q = 0; q < NP / 16; ++q) {
       const int n = (t & 15) + 16 * q;
-      v[q] = (k < K && n < NW && n0 + n < N) ? phi[(size_t)k * N + n0 + n] : 0.0;
+      v[q] = (k < K && n < NW && n0 + n < N) ? phi[(size_t)(k0 + k) * N + n0 + n] : 0.0;
     }
 #pragma unroll
     for (int q = 0; q < NP / 16; ++q) sphi[k * NP + (t & 15) + 16 * q] = v[q];
@@ -71,7 +76,7 @@ __global__ __launch_bounds__(512) void k_tsmm(int64_t ncells, int K, int N, int 
 #pragma unroll
     for (int q = 0; q < CH; ++q) {
       const int k = 4 * (ch * CH + q) + lg;
-      a[q] = (ok && k < K) ? (LAYOUT == 0 ? in[c * K + k] : in[(int64_t)k * ncells + c]) : 0.0;
+      a[q] = (ok && k < K) ? (LAYOUT == 0 ? in[c * Kfull + k0 + k] : in[(int64_t)(k0 + k) * ncells + c]) : 0.0;
     }
   };
   double a_cur[CH], a_nxt[CH], a_nn[CH], pb[NT], pn[NT];
@@ -85,6 +90,22 @@ __global__ __launch_bounds__(512) void k_tsmm(int64_t ncells, int K, int N, int 
     double4_t acc[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[nt] = double4_t{0.0, 0.0, 0.0, 0.0};
+    if (ACC) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (LAYOUT == 0) {
+            const int64_t cc = c0 + lg + 4 * r;
+            const int n = n0 + 16 * nt + lc;
+            if (cc < ncells && n < N) acc[nt][r] = out[cc * N + n];
+          } else {
+            const int n = n0 + 16 * nt + lg + 4 * r;
+            const int64_t cc = c0 + lc;
+            if (cc < ncells && n < N) acc[nt][r] = out[(int64_t)n * ncells + cc];
+          }
+        }
+    }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) pb[nt] = bp[16 * nt];
     for (int ch = 0; ch < nch; ++ch) {
@@ -132,35 +153,32 @@ __global__ __launch_bounds__(512) void k_tsmm(int64_t ncells, int K, int N, int 
 }
 
 template <int NT>
-static int launch_tsmm_t(int layout, int64_t ncells, int K, int N, int n0, const double* in, const double* phi,
-                         double* out, hipStream_t s)
+static int launch_tsmm_t(int layout, int64_t ncells, int Kfull, int N, int n0, int k0, int K, const double* in,
+                         const double* phi, double* out, hipStream_t s)
 {
+
   const int KT = (K + 3) / 4, rows = 4 * kTsmmChunk * ((KT + kTsmmChunk - 1) / kTsmmChunk);
   const int NW = 16 * NT, NP = NW + ((NW & 31) == 16 ? 0 : 16);
   const size_t lds = (size_t)rows * NP * sizeof(double);
   if (lds > 160 * 1024) {
-    set_error("wf_tsmm: K too large for the LDS-staged table (K rounded up to 32, times 144 * 8 B, must fit 160 KB)");
+    set_error("wf_tsmm: row range too large for the LDS-staged table");
     return WF_ERR_UNSUPPORTED;
   }
   const int64_t ntiles = (ncells + 15) / 16;
   const unsigned nb = (unsigned)std::min<int64_t>((ntiles + 7) / 8, 256);
-  if (layout == 0) {
-    auto kern = k_tsmm<NT, 0>;
-    static size_t set0 = 0;
-    if (lds > 64 * 1024 && lds > set0) {
+  auto go = [&](auto kern, size_t& set) -> int {
+    if (lds > 64 * 1024 && lds > set) {
       WF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      set0 = lds;
+      set = lds;
     }
-    hipLaunchKernelGGL(kern, dim3(nb), dim3(512), lds, s, ncells, K, N, n0, in, phi, out);
-  } else {
-    auto kern = k_tsmm<NT, 1>;
-    static size_t set1 = 0;
-    if (lds > 64 * 1024 && lds > set1) {
-      WF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      set1 = lds;
-    }
-    hipLaunchKernelGGL(kern, dim3(nb), dim3(512), lds, s, ncells, K, N, n0, in, phi, out);
-  }
+    hipLaunchKernelGGL(kern, dim3(nb), dim3(512), lds, s, ncells, Kfull, N, n0, k0, K, in, phi, out);
+    return WF_OK;
+  };
+  static size_t set[4] = {0, 0, 0, 0};
+  int rc;
+  if (layout == 0) rc = k0 > 0 ? go(k_tsmm<NT, 0, true>, set[1]) : go(k_tsmm<NT, 0, false>, set[0]);
+  else rc = k0 > 0 ? go(k_tsmm<NT, 1, true>, set[3]) : go(k_tsmm<NT, 1, false>, set[2]);
+  if (rc != WF_OK) return rc;
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     set_error(std::string("wf_tsmm launch failed: ") + hipGetErrorString(e));
@@ -180,15 +198,30 @@ extern "C" int wf_tsmm(int layout, int64_t ncells, int K, int N, const double* d
   WF_REQUIRE(ncells >= 0 && K > 0 && N > 0 && d_in && d_phi && d_out, "wf_tsmm: bad arguments");
   if (ncells == 0) return WF_OK;
   hipStream_t s = (hipStream_t)stream;
-  // columns in passes of at most 128 (8 accumulator tiles per wave)
-  for (int n0 = 0; n0 < N; n0 += 128) {
-    const int nn = std::min(128, N - n0);
-    int rc;
-    if (nn <= 16) rc = launch_tsmm_t<1>(layout, ncells, K, N, n0, d_in, d_phi, d_out, s);
-    else if (nn <= 32) rc = launch_tsmm_t<2>(layout, ncells, K, N, n0, d_in, d_phi, d_out, s);
-    else if (nn <= 64) rc = launch_tsmm_t<4>(layout, ncells, K, N, n0, d_in, d_phi, d_out, s);
-    else rc = launch_tsmm_t<8>(layout, ncells, K, N, n0, d_in, d_phi, d_out, s);
-    if (rc != WF_OK) return rc;
+  // Columns in passes of at most 128 (8 accumulator tiles of 16 per wave), the tiles spread evenly
+  // over the passes (N = 216: 7 + 7 tiles rather than 8 + 6 with two idle); table rows in ranges
+  // of at most 128 (the LDS-resident block is 128 x 144 doubles = 147 KB), whole 32-row chunks
+  // first, later ranges accumulating onto out.  The P5..P7 tables of demo/gpu_operator
+  // (216^2, 343^2, 512^2) take 4 / 9 / 16 launches.
+  const int tiles = (N + 15) / 16, npass = (tiles + 7) / 8, tpp = (tiles + npass - 1) / npass;
+  const int nk = (K + 127) / 128, kc = 32 * (((K + nk - 1) / nk + 31) / 32);
+  for (int n0 = 0; n0 < N; n0 += 16 * tpp) {
+    const int nt = std::min(tpp, (N - n0 + 15) / 16);
+    for (int k0 = 0; k0 < K; k0 += kc) {
+      const int kk = std::min(kc, K - k0);
+      int rc;
+      switch (nt) {
+      case 1: rc = launch_tsmm_t<1>(layout, ncells, K, N, n0, k0, kk, d_in, d_phi, d_out, s); break;
+      case 2: rc = launch_tsmm_t<2>(layout, ncells, K, N, n0, k0, kk, d_in, d_phi, d_out, s); break;
+      case 3:
+      case 4: rc = launch_tsmm_t<4>(layout, ncells, K, N, n0, k0, kk, d_in, d_phi, d_out, s); break;
+      case 5: rc = launch_tsmm_t<5>(layout, ncells, K, N, n0, k0, kk, d_in, d_phi, d_out, s); break;
+      case 6: rc = launch_tsmm_t<6>(layout, ncells, K, N, n0, k0, kk, d_in, d_phi, d_out, s); break;
+      case 7: rc = launch_tsmm_t<7>(layout, ncells, K, N, n0, k0, kk, d_in, d_phi, d_out, s); break;
+      default: rc = launch_tsmm_t<8>(layout, ncells, K, N, n0, k0, kk, d_in, d_phi, d_out, s); break;
+      }
+      if (rc != WF_OK) return rc;
+    }
   }
   return WF_OK;
 }
