@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from wave_fenics_amd import _lib   # noqa: E402
 
-_lib.LIB_PATH = os.path.join(ROOT, "examples", "bin", "libwavehip_trace.so")
+_lib.LIB_PATH = os.environ.get("WAVEHIP_LIB") or os.path.join(ROOT, "examples", "bin", "libwavehip_trace.so")
 from wave_fenics_amd import tet   # noqa: E402
 
 ITERS, SLOTS = 12, 6

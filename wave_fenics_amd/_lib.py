@@ -6,7 +6,9 @@ import os
 from ctypes import POINTER, c_char_p, c_double, c_int, c_int32, c_int64, c_size_t, c_void_p
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libwavehip.so")
+# WAVEHIP_LIB selects another build of the same library (the diagnostic builds of tools/diag_build.sh
+# and tools/dense_trace.sh); there is still no fallback if the file is missing.
+LIB_PATH = os.environ.get("WAVEHIP_LIB") or os.path.join(HERE, "libwavehip.so")
 
 
 class WavehipError(RuntimeError):

@@ -9,6 +9,17 @@
 
 #include "wavehip.h"
 
+// Diagnostic ablation flags (WF_ABLATE environment variable: skip the scatter, serve geometry from
+// L2, ...) are compiled in only with -DWF_DIAG (tools/diag_build.sh).  In the product build the
+// kernels see the constant 0 and every diagnostic branch folds away: as run-time branches they
+// split the hot loops into basic blocks, and at each join the compiler's s_waitcnt bookkeeping
+// turns conservative (measured +13 % on the tetrahedral MFMA kernel).
+#ifdef WF_DIAG
+#define WF_ABLATE_FLAGS(arg) (arg)
+#else
+#define WF_ABLATE_FLAGS(arg) 0
+#endif
+
 namespace wf {
 
 constexpr int kMaxDegree = 7;

@@ -244,8 +244,9 @@ __global__ __launch_bounds__(256) void k_stiffness_generic(int ncells, const int
                                                            const double2* __restrict__ G6blk,
                                                            const double* __restrict__ dD, DMat dm,
                                                            double coeff, const double* __restrict__ x,
-                                                           double* __restrict__ y, int ablate)
+                                                           double* __restrict__ y, int ablate_arg)
 {
+  [[maybe_unused]] const int ablate = WF_ABLATE_FLAGS(ablate_arg);
   constexpr int n = P + 1, n2 = n * n, nd = n * n2;
   constexpr int CB = 256 / n2, NT = CB * n2;
   constexpr int NFLAT = (CB * nd + 255) / 256;
@@ -335,8 +336,9 @@ __global__ __launch_bounds__(256) void k_stiffness_generic_u(int ncells, const i
                                                              const double2* __restrict__ G6blk,
                                                              const double* __restrict__ dD, DMat dm,
                                                              double coeff, const double* __restrict__ x,
-                                                             double* __restrict__ y, int ablate)
+                                                             double* __restrict__ y, int ablate_arg)
 {
+  [[maybe_unused]] const int ablate = WF_ABLATE_FLAGS(ablate_arg);
   constexpr int n = P + 1, n2 = n * n, nd = n * n2;
   constexpr int CB = 256 / n2, NT = CB * n2;
   constexpr int NFLAT = (CB * nd + 255) / 256;
@@ -410,8 +412,9 @@ __global__ __launch_bounds__(256) void k_stiffness_box(int nx, int ny, int nz, i
                                                        const double2* __restrict__ G6blk,
                                                        const double* __restrict__ dD, DMat dm,
                                                        double coeff, const double* __restrict__ x,
-                                                       double* __restrict__ y, int ablate)
+                                                       double* __restrict__ y, int ablate_arg)
 {
+  [[maybe_unused]] const int ablate = WF_ABLATE_FLAGS(ablate_arg);
   constexpr int n = P + 1, n2 = n * n, nd = n * n2;
   const int CB = bx * by * bz, NT = CB * n2;
   const int TX = P * bx + 1, TY = P * by + 1, TZ = P * bz + 1;

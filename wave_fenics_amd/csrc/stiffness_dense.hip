@@ -80,8 +80,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
                                                          const int32_t* __restrict__ uniq,   // unique dofs of all batches
                                                          const uint8_t* __restrict__ clampb, // [nbatch] 1: some w_q C_c of the batch lies in a clamp window
                                                          double coeff, int do_clamp, const double* __restrict__ x,
-                                                         double* __restrict__ y, int ablate, int stagger)
+                                                         double* __restrict__ y, int ablate_arg, int stagger)
 {
+  [[maybe_unused]] const int ablate = WF_ABLATE_FLAGS(ablate_arg);
   constexpr int NQP = 16 * QT, KP = dense_pitch(KT), NT = 64 * NW, NCB = 16 * NW;
   constexpr int DTM = XR > 0 ? DT - 1 : DT, XN = XR > 0 ? XR : 1, KT2 = (KT + 1) / 2;
   extern __shared__ __attribute__((aligned(16))) double smem[];

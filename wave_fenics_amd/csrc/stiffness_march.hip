@@ -33,8 +33,9 @@ __global__ __launch_bounds__(256, (P <= 4 ? 2 : 1)) void k_stiffness_march(int n
                                                             const double* __restrict__ dD, DMat dm,
                                                             double coeff, const double* __restrict__ x,
                                                             double* __restrict__ y,
-                                                            const int32_t* __restrict__ items, int ablate)
+                                                            const int32_t* __restrict__ items, int ablate_arg)
 {
+  [[maybe_unused]] const int ablate = WF_ABLATE_FLAGS(ablate_arg);
   constexpr int n = P + 1, n2 = n * n, nd = n * n2;
   constexpr int CB = BX * BY, NT = CB * n2;
   constexpr int TX = P * BX + 1, TY = P * BY + 1, TP = TX * TY;
@@ -80,12 +81,14 @@ __global__ __launch_bounds__(256, (P <= 4 ? 2 : 1)) void k_stiffness_march(int n
       poff[m] = (int32_t)((size_t)(I0 + I) + (size_t)NX * (J0 + J) + plane * pl);
   }
 
+  const int32_t poff0 = (int32_t)((size_t)I0 + (size_t)NX * J0);   // always inside the mesh
+
   // ---- prologue: geometry of layer z0 -> registers, x planes 0..P -> LDS ------
   double2 gcur[n][3], gnext[n][3];
   auto load_g = [&](double2 (&g)[n][3], int kz) {
     size_t blk = (size_t)Bx + (size_t)nbx * (By + (size_t)nby * kz);
     if (ablate & 2) blk = 0;   // diagnostic: geometry served from L2
-    const double2* gp = G6blk + (blk * n * 3) * (size_t)NT + t;
+    const double2* gp = G6blk + (blk * n * 3) * (size_t)NT + (t < NT ? t : NT - 1);
     if (ablate & 16) {   // diagnostic: ordinary (temporal) geometry loads
 #pragma unroll
       for (int k = 0; k < n; ++k)
@@ -98,7 +101,7 @@ __global__ __launch_bounds__(256, (P <= 4 ? 2 : 1)) void k_stiffness_march(int n
         for (int p = 0; p < 3; ++p) g[k][p] = load_stream(gp + (size_t)(k * 3 + p) * NT);
     }
   };
-  if (active) load_g(gcur, z0);
+  load_g(gcur, z0);
   if (t < n * n) sD[t] = dD[t];
   {
     const size_t base = plane * (size_t)(P * z0);
@@ -125,17 +128,20 @@ __global__ __launch_bounds__(256, (P <= 4 ? 2 : 1)) void k_stiffness_march(int n
     const bool has_next = kz + 1 < z1;
     const size_t base = plane * (size_t)(P * kz);   // first lattice plane of this layer
 
-    // (a) next layer's x planes and geometry: in flight during this layer's arithmetic
+    // (a) next layer's x planes and geometry: in flight during this layer's arithmetic.  The loads
+    // are unconditional, on clamped addresses (positions outside the mesh read the tile's first entry,
+    // idle threads the last thread's geometry, the last layer prefetches itself): a guard around a
+    // load is a branch, and at the join the compiler waits for every memory operation still
+    // pending -- here the previous layer's atomics -- before it issues the prefetch.  What is live
+    // is decided where the registers are consumed, in (c).
+    const int kzn = has_next ? kz + 1 : kz;
     double xn[NPOS];
+    {
+      const double* xb = x + plane * (size_t)(P * kzn) + plane;   // first prefetched plane: P * kzn + 1
 #pragma unroll
-    for (int m = 0; m < NPOS; ++m) {
-      xn[m] = 0.0;
-      if (has_next && poff[m] >= 0) {
-        const size_t gi = base + plane * (P + 1) + poff[m];
-        xn[m] = (ablate & 4) ? 1.0 + m : x[gi];
-      }
+      for (int m = 0; m < NPOS; ++m) xn[m] = (ablate & 4) ? 1.0 + m : xb[poff[m] >= 0 ? poff[m] : poff0];
     }
-    if (has_next && active) load_g(gnext, kz + 1);
+    load_g(gnext, kzn);
 
     // (b) element kernels of the layer
     double out[n];
@@ -154,7 +160,28 @@ __global__ __launch_bounds__(256, (P <= 4 ? 2 : 1)) void k_stiffness_march(int n
     }
     __syncthreads();
 
-    // (c) combine the cells of the layer (fixed order) and add the finished planes to y
+    // (c) rotate the x planes and the geometry registers.  This consumes the prefetched registers and
+    // so carries the wait for the loads issued in (a); it comes BEFORE the flush because loads and
+    // atomics share vmcnt on gfx9 and the compiler waits for vmcnt(0) once both kinds are pending:
+    // placed after the flush, every layer waited for the round trip of its own atomics.
+    if (has_next) {
+#pragma unroll
+      for (int m = 0; m < NCP; ++m) {
+        const int pos = t + 256 * m;
+        if (pos < TP) Ux[pos] = xcp[m];
+      }
+#pragma unroll
+      for (int m = 0; m < NPOS; ++m) {
+        const int pos = t + 256 * m;
+        if (pos < P * TP) Ux[TP + pos] = poff[m] >= 0 ? xn[m] : 0.0;
+      }
+#pragma unroll
+      for (int k = 0; k < n; ++k)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) gcur[k][p] = gnext[k][p];
+    }
+    __builtin_amdgcn_sched_barrier(0);   // keep the copies (and their wait) above the atomics
+    // (d) combine the cells of the layer (fixed order) and add the finished planes to y
 #pragma unroll
     for (int m = 0; m < NPOS; ++m) {
       if (poff[m] < 0) continue;
@@ -178,23 +205,6 @@ __global__ __launch_bounds__(256, (P <= 4 ? 2 : 1)) void k_stiffness_march(int n
       }
     }
 
-    // (d) rotate the x planes and the geometry registers
-    if (has_next) {
-#pragma unroll
-      for (int m = 0; m < NCP; ++m) {
-        const int pos = t + 256 * m;
-        if (pos < TP) Ux[pos] = xcp[m];
-      }
-#pragma unroll
-      for (int m = 0; m < NPOS; ++m) {
-        const int pos = t + 256 * m;
-        if (pos < P * TP) Ux[TP + pos] = xn[m];
-      }
-#pragma unroll
-      for (int k = 0; k < n; ++k)
-#pragma unroll
-        for (int p = 0; p < 3; ++p) gcur[k][p] = gnext[k][p];
-    }
     __syncthreads();
   }
 

@@ -208,7 +208,28 @@ __global__ __launch_bounds__(256, 2) void k_march_idx(int lz, int tile_size, con
     }
     __syncthreads();
 
-    // (c) combine the cells of the layer (fixed order) and add the finished planes to y
+    // (c) rotate the x planes and the geometry registers: the consumers of the prefetched registers
+    // come before the flush, so that their wait does not include this layer's atomics (loads and
+    // atomics share vmcnt; see stiffness_march.hip)
+    if (has_next) {
+#pragma unroll
+      for (int m = 0; m < NCP; ++m) {
+        const int pos = t + 256 * m;
+        if (pos < TP) Ux[pos] = xcp[m];
+      }
+#pragma unroll
+      for (int m = 0; m < NPOS; ++m) {
+        const int pos = t + 256 * m;
+        if (pos < P * TP) Ux[TP + pos] = xn[m];
+      }
+#pragma unroll
+      for (int k = 0; k < n; ++k)
+#pragma unroll
+        for (int p = 0; p < GW; ++p) gcur[k][p] = gnext[k][p];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // (d) combine the cells of the layer (fixed order) and add the finished planes to y
 #pragma unroll
     for (int m = 0; m < NPOS; ++m) {
       const int pos = t + 256 * m;
@@ -229,23 +250,6 @@ __global__ __launch_bounds__(256, 2) void k_march_idx(int lz, int tile_size, con
       unsafeAtomicAdd(y + gbase + off, v);
     }
 
-    // (d) rotate the x planes and the geometry registers
-    if (has_next) {
-#pragma unroll
-      for (int m = 0; m < NCP; ++m) {
-        const int pos = t + 256 * m;
-        if (pos < TP) Ux[pos] = xcp[m];
-      }
-#pragma unroll
-      for (int m = 0; m < NPOS; ++m) {
-        const int pos = t + 256 * m;
-        if (pos < P * TP) Ux[TP + pos] = xn[m];
-      }
-#pragma unroll
-      for (int k = 0; k < n; ++k)
-#pragma unroll
-        for (int p = 0; p < GW; ++p) gcur[k][p] = gnext[k][p];
-    }
     __syncthreads();
   }
 
