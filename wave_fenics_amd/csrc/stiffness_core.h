@@ -17,31 +17,23 @@ __device__ __forceinline__ double2 load_stream(const double2* p)
 }
 
 // --------------------------------------------------------------------------
-// stiffness: per-thread core shared by the generic and the box kernel
+// stiffness: per-thread core shared by the generic, box and marching kernels
 // --------------------------------------------------------------------------
 // U: LDS dofs of this thread's cell, addressed U[k*sk + j*sj + i] (strides in
 // doubles; the generic kernel uses the compact cell layout sk = n^2, sj = n,
 // the box kernel addresses the cell inside the block's dof tile).
 // Fr, Fs: LDS scratch of the cell, compact layout.  sD: LDS copy of D.
-// Output: out[k] = (K_cell u)[i, j, k].  Two workgroup barriers inside.
+// Phase 1: reference gradient at the quadrature points, times G -> Fr, Fs (LDS) and ft
+// (registers).  A workgroup barrier separates it from phase 2, which applies D^T:
+// out[k] = (K_cell u)[i, j, k].  The geometry registers g are dead after phase 1.
 template <int P>
-__device__ __forceinline__ void stiffness_column(const double* __restrict__ U, int sk, int sj,
+__device__ __forceinline__ void stiffness_phase1(const double* __restrict__ U, int sk, int sj,
                                                  double* __restrict__ Fr, double* __restrict__ Fs,
                                                  const double* __restrict__ sD, const DMat& dm,
-                                                 const double2 (&g)[P + 1][3], double coeff, int i,
-                                                 int j, bool active, double (&out)[P + 1], int ablate = 0)
+                                                 const double2 (&g)[P + 1][3], double coeff, int i, int j,
+                                                 bool active, double (&ft)[P + 1])
 {
   constexpr int n = P + 1, n2 = n * n;
-  double ft[n];
-  if (ablate & 8) {   // diagnostic: no contractions, keep every input live
-    if (active) {
-#pragma unroll
-      for (int k = 0; k < n; ++k)
-        out[k] = U[k * sk + j * sj + i] + g[k][0].x + g[k][0].y + g[k][1].x + g[k][1].y + g[k][2].x + g[k][2].y;
-    }
-    __syncthreads();
-    return;
-  }
   if (active) {
     double ru[n];
 #pragma unroll
@@ -71,7 +63,15 @@ __device__ __forceinline__ void stiffness_column(const double* __restrict__ U, i
       Fs[k * n2 + j * n + i] = fs;
     }
   }
-  __syncthreads();
+}
+
+template <int P>
+__device__ __forceinline__ void stiffness_phase2(const double* __restrict__ Fr, const double* __restrict__ Fs,
+                                                 const double* __restrict__ sD, const DMat& dm,
+                                                 const double (&ft)[P + 1], int i, int j, bool active,
+                                                 double (&out)[P + 1])
+{
+  constexpr int n = P + 1, n2 = n * n;
   if (active) {
     double dti[n], dtj[n];
 #pragma unroll
@@ -91,6 +91,30 @@ __device__ __forceinline__ void stiffness_column(const double* __restrict__ U, i
       out[k] = s;
     }
   }
+}
+
+// Both phases with the barrier between them.  Output: out[k] = (K_cell u)[i, j, k].
+template <int P>
+__device__ __forceinline__ void stiffness_column(const double* __restrict__ U, int sk, int sj,
+                                                 double* __restrict__ Fr, double* __restrict__ Fs,
+                                                 const double* __restrict__ sD, const DMat& dm,
+                                                 const double2 (&g)[P + 1][3], double coeff, int i,
+                                                 int j, bool active, double (&out)[P + 1], int ablate = 0)
+{
+  constexpr int n = P + 1;
+  double ft[n];
+  if (ablate & 8) {   // diagnostic: no contractions, keep every input live
+    if (active) {
+#pragma unroll
+      for (int k = 0; k < n; ++k)
+        out[k] = U[k * sk + j * sj + i] + g[k][0].x + g[k][0].y + g[k][1].x + g[k][1].y + g[k][2].x + g[k][2].y;
+    }
+    __syncthreads();
+    return;
+  }
+  stiffness_phase1<P>(U, sk, sj, Fr, Fs, sD, dm, g, coeff, i, j, active, ft);
+  __syncthreads();
+  stiffness_phase2<P>(Fr, Fs, sD, dm, ft, i, j, active, out);
 }
 
 }  // namespace wf

@@ -27,6 +27,12 @@
 
 namespace wf {
 
+// Measured and rejected on cfg2 (P4, 54^3 cells; this kernel 0.226 ms):
+//  * one geometry register set reloaded after phase 1 of the element kernel (168 VGPRs, three
+//    workgroups per CU, deferred flush, two barriers per layer): 0.246 ms with three workgroups per
+//    CU, 0.234 ms with two -- more resident workgroups make the kernel slower, not faster;
+//  * giving each XCD a contiguous range of columns (workgroup b -> item (b % 8) * n / 8 + b / 8)
+//    instead of the round-robin order: 0.247 ms.
 template <int P, int BX, int BY>
 __global__ __launch_bounds__(256, (P <= 4 ? 2 : 1)) void k_stiffness_march(int nx, int ny, int nz, int lz,
                                                             const double2* __restrict__ G6blk,
