@@ -28,9 +28,11 @@
 namespace wf {
 
 // Measured and rejected on cfg2 (P4, 54^3 cells; this kernel 0.226 ms):
-//  * one geometry register set reloaded after phase 1 of the element kernel (168 VGPRs, three
-//    workgroups per CU, deferred flush, two barriers per layer): 0.246 ms with three workgroups per
-//    CU, 0.234 ms with two -- more resident workgroups make the kernel slower, not faster;
+//  * one geometry register set (168 VGPRs, three workgroups per CU, flush deferred past the next
+//    layer's phase 1, two barriers per layer), reloaded either after phase 1 of the element kernel
+//    or triple by triple inside it (prefetch distance a whole layer): 0.246 / 0.249 ms with three
+//    workgroups per CU, 0.234 / 0.230 ms with two -- more resident workgroups make the kernel
+//    slower, not faster;
 //  * giving each XCD a contiguous range of columns (workgroup b -> item (b % 8) * n / 8 + b / 8)
 //    instead of the round-robin order: 0.247 ms.
 template <int P, int BX, int BY>
