@@ -48,7 +48,13 @@ prof kt_rk4 "$R/tools/bench_rk4.py" --steps 10
 prof kt_rk4_periodic "$R/tools/bench_rk4.py" --steps 10 --periodic xyz
 say "generic kernel under hostile orderings"
 python3 "$R/tools/bench_generic_orderings.py" 2>/dev/null > "$OUT/generic_orderings.log"
-say "f64 MFMA rate"
+say "f64 MFMA rate, HBM read rate, TSMM and tet timelines (diagnostic binaries built beforehand into examples/bin)"
 [ -x "$R/examples/bin/mfma_rate" ] && "$R/examples/bin/mfma_rate" > "$OUT/mfma_f64_rate.log"
+[ -x "$R/examples/bin/hbm_read_rate" ] && "$R/examples/bin/hbm_read_rate" > "$OUT/hbm_read_rate.log"
+if [ -x "$R/examples/bin/tsmm_trace" ]; then
+  { echo "== 100000 x 125, layout 0"; "$R/examples/bin/tsmm_trace" 100000 125 0; echo "== 100000 x 125, layout 1"; "$R/examples/bin/tsmm_trace" 100000 125 1;
+    echo "== 1000000 x 125, layout 0"; "$R/examples/bin/tsmm_trace" 1000000 125 0; } > "$OUT/tsmm_trace.log" 2>&1
+fi
+[ -f "$R/examples/bin/libwavehip_trace.so" ] && python3 "$R/tools/dense_trace.py" 2>/dev/null > "$OUT/dense_trace.log"
 find "$OUT" -name "*.csv" | wc -l
 say done

@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256, (P <= 4 ? 2 : 1)) void k_stiffness_march(int n
 
     // (a) next layer's x planes and geometry: in flight during this layer's arithmetic.  The loads
     // are unconditional, on clamped addresses (positions outside the mesh read the tile's first entry,
-    // idle threads the last thread's geometry, the last layer prefetches itself): a guard around a
+    // idle threads the last thread's geometry, the last layer re-reads its own x planes): a guard around a
     // load is a branch, and at the join the compiler waits for every memory operation still
     // pending -- here the previous layer's atomics -- before it issues the prefetch.  What is live
     // is decided where the registers are consumed, in (c).
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256, (P <= 4 ? 2 : 1)) void k_stiffness_march(int n
 #pragma unroll
       for (int m = 0; m < NPOS; ++m) xn[m] = (ablate & 4) ? 1.0 + m : xb[poff[m] >= 0 ? poff[m] : poff0];
     }
-    load_g(gnext, kzn);
+    if (has_next) load_g(gnext, kzn);   // uniform branch; a self-prefetch in the last layer would re-read 1/lz of the geometry
 
     // (b) element kernels of the layer
     double out[n];
