@@ -8,6 +8,8 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+# the WF_ABLATE masks exist only in the diagnostic build of the library (tools/diag_build.sh)
+os.environ.setdefault("WAVEHIP_LIB", os.path.join(ROOT, "examples", "bin", "libwavehip_diag.so"))
 import wave_fenics_amd as w  # noqa: E402
 
 

@@ -1,5 +1,9 @@
+"""Diagnostic: the tetrahedral MFMA kernel under the WF_ABLATE masks (needs the diagnostic build of the
+library, tools/diag_build.sh)."""
 import os, sys
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
+sys.path.insert(0, ROOT)
+os.environ.setdefault("WAVEHIP_LIB", os.path.join(ROOT, "examples", "bin", "libwavehip_diag.so"))
 import numpy as np, torch
 from wave_fenics_amd import tet
 dev = torch.device("cuda", 0)
