@@ -131,7 +131,25 @@ def main():
         # ghost exchange: the C ABI's RCCL updater (grouped ncclSend/ncclRecv per neighbour);
         # WF_UPDATER=torch selects torch.distributed's all_to_all_single on the same index lists
         transport = os.environ.get("WF_UPDATER", "native" if backend == "nccl" else "torch")
-        updater = VectorUpdater(part, device=dev, transport=transport)
+        updater, err = None, ""
+        try:
+            updater = VectorUpdater(part, device=dev, transport=transport)
+        except Exception as e:   # e.g. librccl not loadable by the C ABI: agree on it across ranks below
+            err = f"{type(e).__name__}: {e}"
+        if transport == "native" and world > 1:
+            # every rank must take the same transport: if the native RCCL updater failed anywhere, all
+            # ranks use torch.distributed's RCCL all_to_all on the same index lists (still no host staging)
+            ok = torch.tensor([0 if updater is None else 1], dtype=torch.int32, device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                if rank == 0 or err:
+                    print(f"# rank {rank}: native RCCL updater unavailable ({err or 'failed on another rank'}); "
+                          "using torch.distributed transport", file=sys.stderr, flush=True)
+                if updater is not None:
+                    updater.close() if hasattr(updater, "close") else None
+                updater = VectorUpdater(part, device=dev, transport="torch")
+        elif updater is None:
+            raise RuntimeError(err)
         owned_global = part.size_global
         workload = (f"P{p} hex box, {part.procs[0]}x{part.procs[1]}x{part.procs[2]} partition, {n}^3 cells per GPU, "
                     f"{owned_global} dofs, ghost fwd + stiffness + ghost rev(add) + lumped-mass-inverse apply")

@@ -46,7 +46,21 @@ class Comm:
         if not dist.is_initialized():
             return cls.single()
         rank, size = dist.get_rank(group), dist.get_world_size(group)
-        obj = [cls.unique_id() if rank == 0 else None]
+        # Every rank first proves that it can reach RCCL through the C ABI (ncclGetUniqueId loads the
+        # library) and the ranks agree on the outcome, so that a rank that cannot does not leave the
+        # others waiting in the collectives below.
+        uid, err = None, ""
+        try:
+            uid = cls.unique_id()
+        except Exception as e:
+            err = f"{type(e).__name__}: {e}"
+        import torch
+        flag_dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+        ok = torch.tensor([1 if uid is not None else 0], dtype=torch.int32, device=flag_dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+        if int(ok.item()) == 0:
+            raise _lib.WavehipError("RCCL is not reachable through libwavehip on every rank" + (f" (this rank: {err})" if err else ""))
+        obj = [uid if rank == 0 else None]
         src = dist.get_global_rank(group, 0) if group is not None else 0
         dist.broadcast_object_list(obj, src=src, group=group)
         return cls.create(obj[0], rank, size)
