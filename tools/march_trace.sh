@@ -1,0 +1,14 @@
+#!/bin/bash
+# Diagnostic: build a variant of libwavehip.so whose box marching kernel records per-wave phase
+# timestamps (examples/bin/libwavehip_mtrace.so); tools/march_trace.py runs it and prints the timeline.
+# Extra -D flags (e.g. -DWF_DIAG for the WF_ABLATE masks) can be given as arguments.
+set -e
+R="$(cd "$(dirname "$0")/.." && pwd)"
+C="$R/wave_fenics_amd/csrc"
+python -c "from wave_fenics_amd import build; build.build()"
+mkdir -p "$R/examples/bin"
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -DWF_MARCH_TRACE "$@" -I "$R/include" -I "$C" \
+  -c "$C/stiffness_march.hip" -o "$R/examples/bin/stiffness_march_trace.o"
+OBJS=$(ls "$C"/*.o | grep -v stiffness_march.o)
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$R/examples/bin/libwavehip_mtrace.so" $OBJS "$R/examples/bin/stiffness_march_trace.o" -ldl
+echo "$R/examples/bin/libwavehip_mtrace.so"

@@ -35,6 +35,18 @@ namespace wf {
 //    slower, not faster;
 //  * giving each XCD a contiguous range of columns (workgroup b -> item (b % 8) * n / 8 + b / 8)
 //    instead of the round-robin order: 0.247 ms.
+// Diagnostic build (tools/march_trace.sh): per-wave timestamps of the phases of the first layers of
+// the first 512 workgroups, 100 MHz constant clock.
+#ifdef WF_MARCH_TRACE
+constexpr int kMarchTraceIters = 12, kMarchTraceSlots = 6;
+__device__ unsigned long long g_march_trace[512 * 4 * kMarchTraceIters * kMarchTraceSlots];
+#define WF_MTR(slot)                                                                                          \
+  if ((threadIdx.x & 63) == 0 && trace_it < kMarchTraceIters && blockIdx.x < 512)                              \
+  g_march_trace[((blockIdx.x * 4 + (threadIdx.x >> 6)) * kMarchTraceIters + trace_it) * kMarchTraceSlots + (slot)] = wall_clock64()
+#else
+#define WF_MTR(slot)
+#endif
+
 template <int P, int BX, int BY>
 __global__ __launch_bounds__(256, (P <= 4 ? 2 : 1)) void k_stiffness_march(int nx, int ny, int nz, int lz,
                                                             const double2* __restrict__ G6blk,
@@ -92,8 +104,7 @@ __global__ __launch_bounds__(256, (P <= 4 ? 2 : 1)) void k_stiffness_march(int n
   const int32_t poff0 = (int32_t)((size_t)I0 + (size_t)NX * J0);   // always inside the mesh
 
   // ---- prologue: geometry of layer z0 -> registers, x planes 0..P -> LDS ------
-  double2 gcur[n][3], gnext[n][3];
-  auto load_g = [&](double2 (&g)[n][3], int kz) {
+  auto load_g = [&](double2 (&g)[n][3], int kz, int k0 = 0, int k1 = P + 1) {
     size_t blk = (size_t)Bx + (size_t)nbx * (By + (size_t)nby * kz);
     if (ablate & 2) blk = 0;   // diagnostic: geometry served from L2
     const double2* gp = G6blk + (blk * n * 3) * (size_t)NT + (t < NT ? t : NT - 1);
@@ -101,15 +112,22 @@ __global__ __launch_bounds__(256, (P <= 4 ? 2 : 1)) void k_stiffness_march(int n
 #pragma unroll
       for (int k = 0; k < n; ++k)
 #pragma unroll
-        for (int p = 0; p < 3; ++p) g[k][p] = gp[(size_t)(k * 3 + p) * NT];
+        for (int p = 0; p < 3; ++p)
+          if (k >= k0 && k < k1) g[k][p] = gp[(size_t)(k * 3 + p) * NT];
     } else {
 #pragma unroll
       for (int k = 0; k < n; ++k)
 #pragma unroll
-        for (int p = 0; p < 3; ++p) g[k][p] = load_stream(gp + (size_t)(k * 3 + p) * NT);
+        for (int p = 0; p < 3; ++p)
+          if (k >= k0 && k < k1) g[k][p] = load_stream(gp + (size_t)(k * 3 + p) * NT);
     }
   };
-  load_g(gcur, z0);
+  // the next layer's geometry is requested in three instalments spread over the layer (k planes
+  // [0, G1), [G1, G2), [G2, n)) instead of one burst of 3 n loads at the top
+  // (P4: 0.2209 -> 0.2182 ms; P2 has a third of the geometry per layer and was 5 % slower with it)
+  constexpr int G1 = P >= 4 ? (n + 1) / 3 : n, G2 = P >= 4 ? (2 * n + 1) / 3 : n;
+  double2 gA[n][3], gB[n][3];
+  load_g(gA, z0);
   if (t < n * n) sD[t] = dD[t];
   {
     const size_t base = plane * (size_t)(P * z0);
@@ -132,9 +150,15 @@ __global__ __launch_bounds__(256, (P <= 4 ? 2 : 1)) void k_stiffness_march(int n
   double carry = 0.0;
   const double* Uc = Ux + (P * ly) * TX + P * lx;
 
-  for (int kz = z0; kz < z1; ++kz) {
+  [[maybe_unused]] int trace_it = 0;
+  // One layer; `gcur` holds its geometry, `gnext` receives the next layer's.  The two register sets
+  // swap roles from layer to layer (the loop below is unrolled by two): a copy gcur = gnext is
+  // placed by the compiler at the loop's back edge, behind the flush, and then waits for the
+  // prefetch AND the atomics in front of it.
+  auto layer = [&](double2 (&gcur)[n][3], double2 (&gnext)[n][3], int kz) {
     const bool has_next = kz + 1 < z1;
     const size_t base = plane * (size_t)(P * kz);   // first lattice plane of this layer
+    WF_MTR(0);
 
     // (a) next layer's x planes and geometry: in flight during this layer's arithmetic.  The loads
     // are unconditional, on clamped addresses (positions outside the mesh read the tile's first entry,
@@ -149,11 +173,22 @@ __global__ __launch_bounds__(256, (P <= 4 ? 2 : 1)) void k_stiffness_march(int n
 #pragma unroll
       for (int m = 0; m < NPOS; ++m) xn[m] = (ablate & 4) ? 1.0 + m : xb[poff[m] >= 0 ? poff[m] : poff0];
     }
-    if (has_next) load_g(gnext, kzn);   // uniform branch; a self-prefetch in the last layer would re-read 1/lz of the geometry
+    if (has_next) load_g(gnext, kzn, 0, G1);   // uniform branch; a self-prefetch in the last layer would re-read 1/lz of the geometry
 
+    WF_MTR(1);
     // (b) element kernels of the layer
     double out[n];
-    stiffness_column<P>(Uc, TP, TX, Fr + cl * nd, Fs + cl * nd, sD, dm, gcur, coeff, i, j, active, out, ablate);
+    if (ablate & 8) {
+      stiffness_column<P>(Uc, TP, TX, Fr + cl * nd, Fs + cl * nd, sD, dm, gcur, coeff, i, j, active, out, ablate);
+      if (has_next) load_g(gnext, kzn, G1, G2);
+    } else {
+      double ft[n];
+      stiffness_phase1<P>(Uc, TP, TX, Fr + cl * nd, Fs + cl * nd, sD, dm, gcur, coeff, i, j, active, ft);
+      __syncthreads();
+      if (has_next) load_g(gnext, kzn, G1, G2);
+      stiffness_phase2<P>(Fr + cl * nd, Fs + cl * nd, sD, dm, ft, i, j, active, out);
+    }
+    WF_MTR(2);
     double xcp[NCP];
 #pragma unroll
     for (int m = 0; m < NCP; ++m) {
@@ -167,9 +202,10 @@ __global__ __launch_bounds__(256, (P <= 4 ? 2 : 1)) void k_stiffness_march(int n
       for (int k = 0; k < P; ++k) O[(cl * P + k) * n2 + ji] = out[k];
     }
     __syncthreads();
+    WF_MTR(3);
 
-    // (c) rotate the x planes and the geometry registers.  This consumes the prefetched registers and
-    // so carries the wait for the loads issued in (a); it comes BEFORE the flush because loads and
+    // (c) rotate the x planes.  This consumes the prefetched x registers and so carries the wait for
+    // their loads; it comes BEFORE the flush because loads and
     // atomics share vmcnt on gfx9 and the compiler waits for vmcnt(0) once both kinds are pending:
     // placed after the flush, every layer waited for the round trip of its own atomics.
     if (has_next) {
@@ -183,12 +219,10 @@ __global__ __launch_bounds__(256, (P <= 4 ? 2 : 1)) void k_stiffness_march(int n
         const int pos = t + 256 * m;
         if (pos < P * TP) Ux[TP + pos] = poff[m] >= 0 ? xn[m] : 0.0;
       }
-#pragma unroll
-      for (int k = 0; k < n; ++k)
-#pragma unroll
-        for (int p = 0; p < 3; ++p) gcur[k][p] = gnext[k][p];
     }
-    __builtin_amdgcn_sched_barrier(0);   // keep the copies (and their wait) above the atomics
+    __builtin_amdgcn_sched_barrier(0);   // keep the LDS writes (and the wait for xn) above the atomics
+    if (has_next) load_g(gnext, kzn, G2, n);
+    WF_MTR(4);
     // (d) combine the cells of the layer (fixed order) and add the finished planes to y
 #pragma unroll
     for (int m = 0; m < NPOS; ++m) {
@@ -212,8 +246,14 @@ __global__ __launch_bounds__(256, (P <= 4 ? 2 : 1)) void k_stiffness_march(int n
         unsafeAtomicAdd(dst, v);
       }
     }
+    WF_MTR(5);
+    ++trace_it;
 
     __syncthreads();
+  };
+  for (int kz = z0; kz < z1; kz += 2) {
+    layer(gA, gB, kz);
+    if (kz + 1 < z1) layer(gB, gA, kz + 1);
   }
 
   // ---- epilogue: the last (carried) plane ------------------------------------
@@ -311,3 +351,13 @@ int launch_stiffness_march(int P, int variant, int nx, int ny, int nz, int lz, c
 }
 
 }  // namespace wf
+
+#ifdef WF_MARCH_TRACE
+extern "C" int wf_debug_march_trace(unsigned long long* host, size_t n)
+{
+  void* sym = nullptr;
+  if (hipGetSymbolAddress(&sym, HIP_SYMBOL(wf::g_march_trace)) != hipSuccess) return -1;
+  if (n > sizeof(wf::g_march_trace) / 8) n = sizeof(wf::g_march_trace) / 8;
+  return hipMemcpy(host, sym, n * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+#endif
