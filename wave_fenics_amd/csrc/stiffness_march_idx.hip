@@ -135,26 +135,34 @@ __global__ __launch_bounds__(256, 2) void k_march_idx(int lz, int tile_size, con
   // geometry registers: stiffness 3 x double2 per point (G upper triangle), mass 1 double (detJ w)
   constexpr int GW = OP == OP_STIFFNESS ? 3 : 1;
   using GT = typename std::conditional<OP == OP_STIFFNESS, double2, double>::type;
-  GT gcur[n][GW], gnext[n][GW];
-  auto load_g = [&](GT (&g)[n][GW], int l) {
+  // two register sets that swap roles from layer to layer (the layer loop is unrolled by two): a
+  // copy gcur = gnext ends up at the loop's back edge, behind the flush, and waits for the atomics
+  GT gA[n][GW], gB[n][GW];
+  auto load_g = [&](GT (&g)[n][GW], int l, int k0 = 0, int k1 = P + 1) {
     if constexpr (OP == OP_STIFFNESS) {
       const double2* gp = static_cast<const double2*>(geom) + ((item * lz + l) * n * 3) * (size_t)NT + t;
 #pragma unroll
       for (int k = 0; k < n; ++k)
 #pragma unroll
-        for (int p = 0; p < 3; ++p) g[k][p] = load_stream(gp + (size_t)(k * 3 + p) * NT);
+        for (int p = 0; p < 3; ++p)
+          if (k >= k0 && k < k1) g[k][p] = load_stream(gp + (size_t)(k * 3 + p) * NT);
     } else {
       const double* gp = static_cast<const double*>(geom) + ((item * lz + l) * n) * (size_t)NT + t;
 #pragma unroll
-      for (int k = 0; k < n; ++k) g[k][0] = __builtin_nontemporal_load(gp + (size_t)k * NT);
+      for (int k = 0; k < n; ++k)
+        if (k >= k0 && k < k1) g[k][0] = __builtin_nontemporal_load(gp + (size_t)k * NT);
     }
   };
+  // stiffness at P >= 4: the next layer's geometry is requested in three instalments over the layer
+  // (see stiffness_march.hip)
+  constexpr bool kSpread = OP == OP_STIFFNESS && P >= 4;
+  constexpr int G1 = kSpread ? (n + 1) / 3 : n, G2 = kSpread ? (2 * n + 1) / 3 : n;
   // index table first (L2-resident for regular numberings), then the first layer's geometry and
   // x planes together: one HBM latency in the prologue, not two (loads retire in order)
   if (t < n * n) sD[t] = dD[t];
   for (int e = t; e < (P * nl + 1) * TP; e += 256) sIdx[e] = pat[e];
   __syncthreads();
-  if (active) load_g(gcur, 0);
+  if (active) load_g(gA, 0);
   // ---- prologue: x planes 0..P of the first layer -> LDS ------------------------
 #pragma unroll
   for (int m = 0; m < NPOS0; ++m) {
@@ -169,7 +177,7 @@ __global__ __launch_bounds__(256, 2) void k_march_idx(int lz, int tile_size, con
   double carry = 0.0;
   const double* Uc = Ux + (P * ly) * TX + P * lx;
 
-  for (int l = 0; l < nl; ++l) {
+  auto layer = [&](GT (&gcur)[n][GW], GT (&gnext)[n][GW], int l) {
     const bool has_next = l + 1 < nl;
     // (a) next layer's x planes and geometry: in flight during this layer's arithmetic
     double xn[NPOS];
@@ -182,12 +190,16 @@ __global__ __launch_bounds__(256, 2) void k_march_idx(int lz, int tile_size, con
         if (off >= 0) xn[m] = x[gbase + off];
       }
     }
-    if (has_next && active) load_g(gnext, l + 1);
+    if (has_next && active) load_g(gnext, l + 1, 0, G1);
 
     // (b) element kernels of the layer
     double out[n];
     if constexpr (OP == OP_STIFFNESS) {
-      stiffness_column<P>(Uc, TP, TX, Fr + cl * nd, Fs + cl * nd, sD, dm, gcur, coeff, i, j, active, out);
+      double ft[n];
+      stiffness_phase1<P>(Uc, TP, TX, Fr + cl * nd, Fs + cl * nd, sD, dm, gcur, coeff, i, j, active, ft);
+      __syncthreads();
+      if (kSpread && has_next && active) load_g(gnext, l + 1, G1, G2);
+      stiffness_phase2<P>(Fr + cl * nd, Fs + cl * nd, sD, dm, ft, i, j, active, out);
     } else {
       double djk[n];
 #pragma unroll
@@ -208,7 +220,7 @@ __global__ __launch_bounds__(256, 2) void k_march_idx(int lz, int tile_size, con
     }
     __syncthreads();
 
-    // (c) rotate the x planes and the geometry registers, (d) combine the cells of the layer (fixed
+    // (c) rotate the x planes, (d) combine the cells of the layer (fixed
     // order) and add the finished planes to y.  For the stiffness operator the rotation -- the
     // consumers of the prefetched registers -- comes before the flush, so that its wait does not
     // include this layer's atomics (loads and atomics share vmcnt; see stiffness_march.hip).
@@ -224,10 +236,6 @@ __global__ __launch_bounds__(256, 2) void k_march_idx(int lz, int tile_size, con
         const int pos = t + 256 * m;
         if (pos < P * TP) Ux[TP + pos] = xn[m];
       }
-#pragma unroll
-      for (int k = 0; k < n; ++k)
-#pragma unroll
-        for (int p = 0; p < GW; ++p) gcur[k][p] = gnext[k][p];
     }
     };
     auto flush = [&]() {
@@ -261,10 +269,15 @@ __global__ __launch_bounds__(256, 2) void k_march_idx(int lz, int tile_size, con
     } else {
       rotate();
       __builtin_amdgcn_sched_barrier(0);
+      if (kSpread && has_next && active) load_g(gnext, l + 1, G2, n);
       flush();
     }
 
     __syncthreads();
+  };
+  for (int l = 0; l < nl; l += 2) {
+    layer(gA, gB, l);
+    if (l + 1 < nl) layer(gB, gA, l + 1);
   }
 
   // ---- epilogue: the last (carried) plane ------------------------------------
