@@ -94,12 +94,13 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
   (void)nq;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int lc = lane & 15, lg = lane >> 4;
-  // Two workgroups share a CU (one wave of each per SIMD).  Started together they stay in phase:
-  // both in their MFMA sections (sharing the pipe), then both in the gather / scatter phases with
-  // the pipe idle (tools/dense_trace.py: 13.7 + 7.9 us per batch).  The second resident workgroup of
-  // a CU (dispatch order: blockIdx >= number of CUs) therefore starts half a batch late, so that one
-  // workgroup's scatter / gather runs under the other's MFMA section.
-  if ((blockIdx.x / 256) & 1) {
+  // Two workgroups share a CU (one wave of each per SIMD; workgroups b and b + 256, per HW_ID in
+  // tools/dense_trace.py).  Experiment knob WF_DENSE_STAGGER (default 0 = off): start the second
+  // resident workgroup half a batch late so that its gather / scatter phases fall under the other's
+  // MFMA section.  It gains nothing (0.600 / 0.607 / 0.614 ms at 0 / 1 / 2 sleeps before the other
+  // changes of the round): the phase offset persists, but a lone wave keeps the MFMA pipe only 57 %
+  // busy -- barely more than half of the saturated pipe two overlapping MFMA sections share.
+  if (stagger > 0 && ((blockIdx.x / 256) & 1)) {
     for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(127);   // 127 * 64 cycles each
   }
   for (int p = t; p < 3 * NQP * KP; p += NT) T[p] = Tg[p];
@@ -531,7 +532,7 @@ static int launch_dense_t(const DenseOpData* d, double coeff, int do_clamp, cons
   hipLaunchKernelGGL(kern, dim3(nb), dim3(64 * NW), lds, s, d->nd, d->nq, d->nbatch, d->numax, d->d_T, d->d_w, d->d_C,
                      d->d_locP, d->d_uoff, d->d_uniq, d->d_clampb, coeff, do_clamp, d_x, d_y,
                      std::getenv("WF_ABLATE") ? std::atoi(std::getenv("WF_ABLATE")) : 0,
-                     std::getenv("WF_DENSE_STAGGER") ? std::atoi(std::getenv("WF_DENSE_STAGGER")) : 2);
+                     std::getenv("WF_DENSE_STAGGER") ? std::atoi(std::getenv("WF_DENSE_STAGGER")) : 0);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     set_error(std::string("stiffness_dense launch failed: ") + hipGetErrorString(e));
