@@ -207,7 +207,6 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     WF_DTR(1);
     // gather of the next batch (registers) and index list of the one after it
     int32_t uq_nn[NU];
-    load_x(xr, uq_nxt);
     load_cell(locn, Cn, batch + G);
     load_uq(uq_nn, rg2);
     const int nu_nn = count_of(rg2);
@@ -252,6 +251,11 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         for (int e = 0; e < 3; ++e) W[e] = __builtin_amdgcn_mfma_f64_16x16x4f64(a3[ks % 3][e], ub[ks], W[e], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
+      // the x gather of the next batch (NU scattered 8-byte loads per thread, up to 64 cache lines per
+      // wave instruction) goes out behind the first product of the first slab, not in front of the
+      // MFMA section: a wave blocks in the issue of such a burst (the CU's outstanding-request
+      // capacity), and here its 27 queued MFMAs cover that
+      if (qt == 0) load_x(xr, uq_nxt);
       // first A operands of the second product: in flight during the lane-local geometry product
       // (row = e NQP + 16 qt + pi(4 r + lg), column d = 16 dt + lc; columns >= 4 KT are never stored: pad = 0)
       // accumulator register r of lane group lg is quadrature point pi(4 r + lg) = 2 r + pi(lg) of the slab
