@@ -2,9 +2,11 @@
 //     out[cell][n] = sum_k in[cell][k] * phi[k][n]
 // the two cublasDgemm calls of demo/gpu_tsmm/main.cpp:49-52 (100000 x 125 times
 // 125 x 125) and the "B" / "B^T" products of demo/gpu_operator/main.cpp:149-155,
-// on v_mfma_f64_16x16x4_f64.  phi (K x N, <= 150 KB) is staged once per workgroup
-// in LDS; one wave owns 16 cells and keeps all ceil(N/16) accumulator tiles in
-// registers; a persistent grid of one 512-thread workgroup per CU walks the cells.
+// on v_mfma_f64_16x16x4_f64.  A block of phi (<= 128 rows x 128 columns, <= 150 KB)
+// is staged once per workgroup in LDS; one wave owns 16 cells and keeps the block's
+// accumulator tiles (<= 8) in registers; a persistent grid of one 512-thread
+// workgroup per CU walks the cells.  Larger tables run as several launches: column
+// passes, and row ranges that accumulate onto out (wf_tsmm below).
 //
 // layout 0 (cell-major, demo/gpu_operator): in[cell*K + k], out[cell*N + n];
 //          A operand = in tile (16 cells x 4 k), B operand = phi.
