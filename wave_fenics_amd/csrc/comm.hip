@@ -128,6 +128,7 @@ struct wf_updater {
   // pack / RCCL / unpack kernels never queue behind the interior's resident workgroups
   hipStream_t side_stream = nullptr;
   hipStream_t interior_stream = nullptr;      // nullptr: interior runs on the caller's stream
+  hipStream_t low_stream = nullptr;           // low-priority stream for the interior when the halo chain runs on the caller's
   hipEvent_t ev_main = nullptr, ev_side = nullptr, ev_interior = nullptr;
 };
 
@@ -146,6 +147,7 @@ void free_updater(wf_updater* u)
   if (u->ev_side) (void)hipEventDestroy(u->ev_side);
   if (u->ev_interior) (void)hipEventDestroy(u->ev_interior);
   if (u->interior_stream) (void)hipStreamDestroy(u->interior_stream);
+  if (u->low_stream) (void)hipStreamDestroy(u->low_stream);
   if (u->comm_stream) (void)hipStreamDestroy(u->comm_stream);
   if (u->side_stream) (void)hipStreamDestroy(u->side_stream);
   delete u;
@@ -396,6 +398,7 @@ int wf_updater_create(wf_comm* comm, const wf_updater_desc* desc, wf_updater** o
   WF_HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
   WF_HIP_CHECK(hipStreamCreateWithPriority(&u->comm_stream, hipStreamNonBlocking, prio_high));
   WF_HIP_CHECK(hipStreamCreateWithPriority(&u->side_stream, hipStreamNonBlocking, prio_high));
+  WF_HIP_CHECK(hipStreamCreateWithPriority(&u->low_stream, hipStreamNonBlocking, prio_low));
   // Optional: CUs kept free of interior workgroups through a CU-masked stream
   // (WF_OVERLAP_RESERVE_CUS = n).  Measured on MI355X (bench.py --periodic x, ms per step):
   // n = 0: 0.346, n = 4 or 8: 0.476 -- the halo chain then starts at once (RCCL kernel 12 us instead
@@ -491,9 +494,28 @@ int wf_op_apply_overlapped(wf_op* op, wf_updater* u, double* d_x, double* d_y, v
 {
   WF_REQUIRE(op && u && d_x && d_y, "wf_op_apply_overlapped: null argument");
   hipStream_t main = (hipStream_t)stream, side = u->side_stream;
+  int rc;
+  // Default: the halo chain (pack, RCCL, unpack, interface cells, and the same in reverse) runs on
+  // the CALLER's stream and the interior cells on a low-priority stream of the updater.  The chain
+  // is the longer of the two, so the caller's stream continues behind the reverse unpack with no
+  // cross-stream wait on the critical path (the interior finished earlier; waiting on a signalled
+  // event is free), where the mirror arrangement paid ~17 us of event latency before the next
+  // kernel (rocprofv3 kernel trace of bench.py --periodic xyz).  WF_OVERLAP_CHAIN_ON_SIDE=1 selects
+  // the mirror arrangement (chain on the updater's high-priority stream, interior on the caller's).
+  static const bool chain_on_side = std::getenv("WF_OVERLAP_CHAIN_ON_SIDE") != nullptr;
+  if (!chain_on_side && !u->interior_stream) {
+    WF_HIP_CHECK(hipEventRecord(u->ev_main, main));
+    WF_HIP_CHECK(hipStreamWaitEvent(u->low_stream, u->ev_main, 0));
+    if ((rc = wf_op_apply_part(op, d_x, d_y, WF_PART_INTERIOR, u->low_stream)) != WF_OK) return rc;
+    WF_HIP_CHECK(hipEventRecord(u->ev_interior, u->low_stream));
+    if ((rc = fwd_begin(u, d_x, main, true)) != WF_OK || (rc = fwd_end(u, d_x, main, true)) != WF_OK) return rc;
+    if ((rc = wf_op_apply_part(op, d_x, d_y, WF_PART_INTERFACE, main)) != WF_OK) return rc;
+    if ((rc = rev_begin(u, d_y, main, true)) != WF_OK || (rc = rev_end(u, d_y, main, true)) != WF_OK) return rc;
+    WF_HIP_CHECK(hipStreamWaitEvent(main, u->ev_interior, 0));
+    return WF_OK;
+  }
   WF_HIP_CHECK(hipEventRecord(u->ev_main, main));
   WF_HIP_CHECK(hipStreamWaitEvent(side, u->ev_main, 0));
-  int rc;
   // the side stream IS the communication stream here: exchanges are enqueued on it directly
   if ((rc = fwd_begin(u, d_x, side, true)) != WF_OK || (rc = fwd_end(u, d_x, side, true)) != WF_OK) return rc;
   if ((rc = wf_op_apply_part(op, d_x, d_y, WF_PART_INTERFACE, side)) != WF_OK) return rc;
