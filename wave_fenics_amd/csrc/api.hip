@@ -14,6 +14,7 @@ struct wf_op {
   int structured = 0, nx = 0, ny = 0, nz = 0, bx = 1, by = 1, bz = 1;
   int nq1 = 0;
   int march = 0, march_variant = 0, lz = 1;   // marching box kernel (stiffness_march.hip)
+  int lz0_split = 1;                          // length of the first z segment of the interior / interface parts
   double coeff = 0.0;
   DMat dm{};
   int32_t* d_dofmap = nullptr;
@@ -896,7 +897,7 @@ int wf_op_apply(wf_op* op, const double* d_x, double* d_y, void* stream)
   if (op->dense) return launch_stiffness_dense(op->dense, op->coeff, op->dense_clamp, d_x, d_y, s);
   if (op->structured) {
     if (op->kind == WF_OP_STIFFNESS && op->march)
-      return launch_stiffness_march(op->P, op->march_variant, op->nx, op->ny, op->nz, op->lz, op->d_G6blk, op->d_D,
+      return launch_stiffness_march(op->P, op->march_variant, op->nx, op->ny, op->nz, op->lz, op->lz, op->d_G6blk, op->d_D,
                                     op->dm, op->coeff, d_x, d_y, nullptr, 0, s);
     if (op->kind == WF_OP_STIFFNESS)
       return launch_stiffness_box(op->P, op->nx, op->ny, op->nz, op->bx, op->by, op->bz, op->d_G6blk, op->d_D, op->dm,
@@ -939,7 +940,16 @@ int wf_op_set_ghost_faces(wf_op* op, int ghost_x0, int ghost_y0, int ghost_z0)
     return WF_ERR_UNSUPPORTED;
   }
   const int nbx = (op->nx + op->bx - 1) / op->bx, nby = (op->ny + op->by - 1) / op->by;
-  const int ncols = nbx * nby, nseg = (op->nz + op->lz - 1) / op->lz;
+  // With a ghost plane below, the first z segment is kept short (WF_MARCH_LZ0, default 3 layers):
+  // only its first layer reads the ghost plane, but the whole segment has to wait for the halo, and
+  // the less interface work there is the earlier the reverse exchange can start under the interior.
+  op->lz0_split = op->lz;
+  if (ghost_z0) {
+    int lz0 = 3;
+    if (const char* e = std::getenv("WF_MARCH_LZ0")) lz0 = std::atoi(e);
+    op->lz0_split = std::max(1, std::min(lz0, op->lz));
+  }
+  const int ncols = nbx * nby, nseg = 1 + (std::max(op->nz - op->lz0_split, 0) + op->lz - 1) / op->lz;
   std::vector<int32_t> items[4];
   for (int seg = 0; seg < nseg; ++seg)
     for (int col = 0; col < ncols; ++col) {
@@ -975,8 +985,8 @@ int wf_op_apply_part(wf_op* op, const double* d_x, double* d_y, int part, void* 
   }
   const int k = part - 1;   // WF_PART_INTERIOR, _INTERFACE, _INTERIOR_A, _INTERIOR_B
   if (op->nitems[k] == 0) return WF_OK;
-  return launch_stiffness_march(op->P, op->march_variant, op->nx, op->ny, op->nz, op->lz, op->d_G6blk, op->d_D, op->dm,
-                                op->coeff, d_x, d_y, op->d_items[k], op->nitems[k], (hipStream_t)stream);
+  return launch_stiffness_march(op->P, op->march_variant, op->nx, op->ny, op->nz, op->lz, op->lz0_split, op->d_G6blk, op->d_D,
+                                op->dm, op->coeff, d_x, d_y, op->d_items[k], op->nitems[k], (hipStream_t)stream);
 }
 
 int wf_op_info(const wf_op* op, wf_op_info_t* info)

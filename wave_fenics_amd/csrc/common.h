@@ -78,7 +78,7 @@ int launch_stiffness_box(int P, int nx, int ny, int nz, int bx, int by, int bz, 
                          const double* d_D, const DMat& dm, double coeff, const double* d_x, double* d_y,
                          hipStream_t s);
 bool march_variant(int P, int variant, int* bx, int* by);
-int launch_stiffness_march(int P, int variant, int nx, int ny, int nz, int lz, const double* d_G6blk,
+int launch_stiffness_march(int P, int variant, int nx, int ny, int nz, int lz, int lz0, const double* d_G6blk,
                            const double* d_D, const DMat& dm, double coeff, const double* d_x, double* d_y,
                            const int32_t* d_items, int nitems, hipStream_t s);
 // indexed marching kernel for arbitrary dofmaps (generic_plan.cpp, stiffness_march_idx.hip)

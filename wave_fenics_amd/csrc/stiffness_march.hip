@@ -48,7 +48,7 @@ __device__ unsigned long long g_march_trace[512 * 4 * kMarchTraceIters * kMarchT
 #endif
 
 template <int P, int BX, int BY>
-__global__ __launch_bounds__(256, (P <= 4 ? 2 : 1)) void k_stiffness_march(int nx, int ny, int nz, int lz,
+__global__ __launch_bounds__(256, (P <= 4 ? 2 : 1)) void k_stiffness_march(int nx, int ny, int nz, int lz, int lz0,
                                                             const double2* __restrict__ G6blk,
                                                             const double* __restrict__ dD, DMat dm,
                                                             double coeff, const double* __restrict__ x,
@@ -78,7 +78,9 @@ __global__ __launch_bounds__(256, (P <= 4 ? 2 : 1)) void k_stiffness_march(int n
   const int item = items ? items[blockIdx.x] : (int)blockIdx.x;
   const int col = item % ncols, seg = item / ncols;
   const int Bx = col % nbx, By = col / nbx;
-  const int z0 = seg * lz, z1 = min(nz, z0 + lz);
+  // z segments: [0, lz0), then pieces of lz layers (lz0 = lz unless the operator is split for the
+  // ghost exchange: a short first segment keeps the work that reads the z ghost plane small)
+  const int z0 = seg == 0 ? 0 : lz0 + (seg - 1) * lz, z1 = min(nz, seg == 0 ? lz0 : z0 + lz);
   const bool active = t < NT;
   const int cl = t / n2, ji = t % n2, j = ji / n, i = ji % n;
   const int lx = cl % BX, ly = cl / BX;
@@ -294,15 +296,15 @@ static int march_ablate()
 }
 
 template <int P, int BX, int BY>
-static int launch_march_t(int nx, int ny, int nz, int lz, const double* d_G6blk, const double* d_D,
+static int launch_march_t(int nx, int ny, int nz, int lz, int lz0, const double* d_G6blk, const double* d_D,
                           const DMat& dm, double coeff, const double* d_x, double* d_y, const int32_t* d_items,
                           int nitems, hipStream_t s)
 {
   const int ncols = ((nx + BX - 1) / BX) * ((ny + BY - 1) / BY);
-  const int nseg = (nz + lz - 1) / lz;
+  const int nseg = 1 + (std::max(nz - lz0, 0) + lz - 1) / lz;
   const int nwg = d_items ? nitems : ncols * nseg;
   if (nwg == 0) return WF_OK;
-  hipLaunchKernelGGL((k_stiffness_march<P, BX, BY>), dim3((unsigned)nwg), dim3(256), 0, s, nx, ny, nz, lz,
+  hipLaunchKernelGGL((k_stiffness_march<P, BX, BY>), dim3((unsigned)nwg), dim3(256), 0, s, nx, ny, nz, lz, lz0,
                      reinterpret_cast<const double2*>(d_G6blk), d_D, dm, coeff, d_x, d_y, d_items, march_ablate());
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
@@ -332,9 +334,9 @@ bool march_variant(int P, int variant, int* bx, int* by)
 }
 
 #define WF_MARCH_CASE(PP, V, BXX, BYY) \
-  if (P == PP && variant == V) return launch_march_t<PP, BXX, BYY>(nx, ny, nz, lz, d_G6blk, d_D, dm, coeff, d_x, d_y, d_items, nitems, s);
+  if (P == PP && variant == V) return launch_march_t<PP, BXX, BYY>(nx, ny, nz, lz, lz0, d_G6blk, d_D, dm, coeff, d_x, d_y, d_items, nitems, s);
 
-int launch_stiffness_march(int P, int variant, int nx, int ny, int nz, int lz, const double* d_G6blk,
+int launch_stiffness_march(int P, int variant, int nx, int ny, int nz, int lz, int lz0, const double* d_G6blk,
                            const double* d_D, const DMat& dm, double coeff, const double* d_x, double* d_y,
                            const int32_t* d_items, int nitems, hipStream_t s)
 {
