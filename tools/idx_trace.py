@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Diagnostic: phase timeline of the indexed marching kernel (k_march_idx) for the dense mass or the
+generic stiffness operator, from a library built with -DWF_IDX_TRACE
+(examples/bin/libwavehip_itrace.so; see tools/march_trace.sh for the recipe).
+usage: idx_trace.py mass|stiffness [P]"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from wave_fenics_amd import _lib   # noqa: E402
+
+_lib.LIB_PATH = os.environ.get("WAVEHIP_LIB") or os.path.join(ROOT, "examples", "bin", "libwavehip_itrace.so")
+import wave_fenics_amd as w   # noqa: E402
+
+ITERS, SLOTS = 12, 6
+
+
+def main():
+    kind = sys.argv[1] if len(sys.argv) > 1 else "mass"
+    p = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+    n = 216 // p
+    dev = torch.device("cuda", 0)
+    V = w.create_functionspace(w.create_box(n), p, build_dofmap=True)
+    V.structured = False
+    if kind == "mass":
+        # square 1-D table (p + 1 Gauss points, equispaced nodes): the marching path of the dense mass operator
+        gx, gw = np.polynomial.legendre.leggauss(p + 1)
+        qp, qw = 0.5 * (gx + 1), 0.5 * gw
+        nodes = np.linspace(0, 1, p + 1)
+        phi1 = np.array([[np.prod([(q - nodes[m]) / (nodes[a] - nodes[m]) for m in range(p + 1) if m != a]) for a in range(p + 1)] for q in qp])
+        W3 = np.einsum("k,j,i->kji", qw, qw, qw).reshape(-1)
+        mesh = V.mesh if hasattr(V, "mesh") else None
+        ncells = n ** 3
+        detq = np.tile(W3 / ncells, (ncells, 1))
+        op = w.MassOperator(V, p, phi1, detq)
+        names = ["(a) issue prefetch", "(b) mass_column (3 barriers)", "O write + barrier", "flush (atomics)", "rotate (waits for prefetch)", "end barrier"]
+    else:
+        op = w.StiffnessOperator(V, p, {"c0": 1500.0})
+        names = ["(a) issue prefetch", "(b) element kernels", "O write + barrier", "rotate", "flush (atomics)", "end barrier"]
+    x = torch.rand(V.ndofs, dtype=torch.float64, device=dev)
+    y = torch.zeros(V.ndofs, dtype=torch.float64, device=dev)
+    for _ in range(3):
+        op(x, y)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    op(x, y)
+    e1.record()
+    torch.cuda.synchronize()
+    print(f"{kind} P{p}, {V.ndofs} dofs: apply {e0.elapsed_time(e1):.4f} ms (with the timestamp stores)")
+    L = _lib.lib()
+    buf = np.zeros(512 * 4 * ITERS * SLOTS, dtype=np.uint64)
+    L.wf_debug_idx_trace.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+    assert L.wf_debug_idx_trace(buf.ctypes.data, buf.size) == 0
+    t = buf.reshape(512, 4, ITERS, SLOTS).astype(np.float64) * 0.01   # us
+    t = np.where(t > 0, t - t[t > 0].min(), np.nan)
+    for k in range(5):
+        d = t[:, :, 1:, k + 1] - t[:, :, 1:, k]
+        print(f"{names[k]:40s} median {np.nanmedian(d):6.2f} us   p10 {np.nanpercentile(d, 10):6.2f}   p90 {np.nanpercentile(d, 90):6.2f}")
+    d = t[:, :, 2:, 0] - t[:, :, 1:-1, 5]
+    print(f"{names[5]:40s} median {np.nanmedian(d):6.2f} us   p10 {np.nanpercentile(d, 10):6.2f}   p90 {np.nanpercentile(d, 90):6.2f}")
+    d = t[:, :, 2:, 0] - t[:, :, 1:-1, 0]
+    print(f"{'whole layer':40s} median {np.nanmedian(d):6.2f} us   p10 {np.nanpercentile(d, 10):6.2f}   p90 {np.nanpercentile(d, 90):6.2f}")
+
+
+if __name__ == "__main__":
+    main()

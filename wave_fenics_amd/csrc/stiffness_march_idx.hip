@@ -99,6 +99,18 @@ __device__ __forceinline__ void mass_column(const double* __restrict__ U, int sk
   }
 }
 
+// Diagnostic build (tools/march_trace.sh -DWF_IDX_TRACE): per-wave timestamps of the phases of the
+// first layers of the first 512 workgroups, 100 MHz constant clock.
+#ifdef WF_IDX_TRACE
+constexpr int kIdxTraceIters = 12, kIdxTraceSlots = 6;
+__device__ unsigned long long g_idx_trace[512 * 4 * kIdxTraceIters * kIdxTraceSlots];
+#define WF_ITR(slot)                                                                                       \
+  if ((threadIdx.x & 63) == 0 && trace_it < kIdxTraceIters && blockIdx.x < 512)                             \
+  g_idx_trace[((blockIdx.x * 4 + (threadIdx.x >> 6)) * kIdxTraceIters + trace_it) * kIdxTraceSlots + (slot)] = wall_clock64()
+#else
+#define WF_ITR(slot)
+#endif
+
 template <int OP, int P, int BX, int BY>
 __global__ __launch_bounds__(256, 2) void k_march_idx(int lz, int tile_size, const int32_t* __restrict__ item_base,
                                                                 const int32_t* __restrict__ item_pattern,
@@ -177,8 +189,10 @@ __global__ __launch_bounds__(256, 2) void k_march_idx(int lz, int tile_size, con
   double carry = 0.0;
   const double* Uc = Ux + (P * ly) * TX + P * lx;
 
+  [[maybe_unused]] int trace_it = 0;
   auto layer = [&](GT (&gcur)[n][GW], GT (&gnext)[n][GW], int l) {
     const bool has_next = l + 1 < nl;
+    WF_ITR(0);
     // (a) next layer's x planes and geometry: in flight during this layer's arithmetic
     double xn[NPOS];
 #pragma unroll
@@ -192,6 +206,7 @@ __global__ __launch_bounds__(256, 2) void k_march_idx(int lz, int tile_size, con
     }
     if (has_next && active) load_g(gnext, l + 1, 0, G1);
 
+    WF_ITR(1);
     // (b) element kernels of the layer
     double out[n];
     if constexpr (OP == OP_STIFFNESS) {
@@ -206,6 +221,7 @@ __global__ __launch_bounds__(256, 2) void k_march_idx(int lz, int tile_size, con
       for (int k = 0; k < n; ++k) djk[k] = gcur[k][0];
       mass_column<P>(Uc, TP, TX, Fr + cl * nd, Fs + cl * nd, sD, dm, djk, i, j, active, out);
     }
+    WF_ITR(2);
     double xcp[NCP];
 #pragma unroll
     for (int m = 0; m < NCP; ++m) {
@@ -219,6 +235,7 @@ __global__ __launch_bounds__(256, 2) void k_march_idx(int lz, int tile_size, con
       for (int k = 0; k < P; ++k) O[(cl * P + k) * n2 + ji] = out[k];
     }
     __syncthreads();
+    WF_ITR(3);
 
     // (c) rotate the x planes, (d) combine the cells of the layer (fixed
     // order) and add the finished planes to y.  For the stiffness operator the rotation -- the
@@ -265,13 +282,17 @@ __global__ __launch_bounds__(256, 2) void k_march_idx(int lz, int tile_size, con
     constexpr bool flush_first = OP == OP_MASS;
     if constexpr (flush_first) {
       flush();
+      WF_ITR(4);
       rotate();
     } else {
       rotate();
       __builtin_amdgcn_sched_barrier(0);
+      WF_ITR(4);
       if (kSpread && has_next && active) load_g(gnext, l + 1, G2, n);
       flush();
     }
+    WF_ITR(5);
+    ++trace_it;
 
     __syncthreads();
   };
@@ -366,3 +387,13 @@ int launch_mass_march_idx(int P, const MarchPlanDev& pd, const double* d_detJblk
 }
 
 }  // namespace wf
+
+#ifdef WF_IDX_TRACE
+extern "C" int wf_debug_idx_trace(unsigned long long* host, size_t n)
+{
+  void* sym = nullptr;
+  if (hipGetSymbolAddress(&sym, HIP_SYMBOL(wf::g_idx_trace)) != hipSuccess) return -1;
+  if (n > sizeof(wf::g_idx_trace) / 8) n = sizeof(wf::g_idx_trace) / 8;
+  return hipMemcpy(host, sym, n * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+#endif
