@@ -32,7 +32,8 @@ namespace wf {
 //    layer's phase 1, two barriers per layer), reloaded either after phase 1 of the element kernel
 //    or triple by triple inside it (prefetch distance a whole layer): 0.246 / 0.249 ms with three
 //    workgroups per CU, 0.234 / 0.230 ms with two -- more resident workgroups make the kernel
-//    slower, not faster;
+//    slower, not faster (a later spill-free build of the second variant, 166 VGPRs, flush values
+//    parked in LDS: 0.228 ms with three per CU against 0.221 ms for this kernel);
 //  * giving each XCD a contiguous range of columns (workgroup b -> item (b % 8) * n / 8 + b / 8)
 //    instead of the round-robin order: 0.247 ms.
 // Diagnostic build (tools/march_trace.sh): per-wave timestamps of the phases of the first layers of
