@@ -86,6 +86,13 @@ def main():
                     "(rehearses the multi-GPU exchange + overlap path on one GPU; not the headline configuration)")
     args = ap.parse_args()
 
+    # stdout carries exactly one line, the JSON record of rank 0.  Libraries that print on
+    # file descriptor 1 (RCCL writes a five-line version banner there when a communicator is created,
+    # once per rank) are sent to stderr for the duration of the run.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -265,7 +272,8 @@ def main():
             except Exception as e:  # the baseline is reported, never required for the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "dofs/s", "cores": 0, "kind": "port",
                                        "sample": f"failed: {e}"}
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if world > 1:
         dist.destroy_process_group()
 
