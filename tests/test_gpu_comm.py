@@ -127,6 +127,40 @@ def test_periodic_stiffness_vs_oracle(gpu, comm, oracle, p, n, periodic, perturb
         assert err <= 1e-12, (mode, err)
 
 
+@pytest.mark.parametrize("lz,lz0", [(7, 2), (5, 1), (6, 6)])
+def test_overlapped_apply_short_first_segment(gpu, comm, oracle, monkeypatch, lz, lz0):
+    """The split operator's z segmentation [0, lz0), then pieces of lz layers (the short first
+    segment keeps the work that waits for the z halo small): wf_op_apply_overlapped on a fully
+    periodic mesh with the segment lengths forced, against the oracle; lz0 = lz is the unsplit layout."""
+    import torch
+    import wave_fenics_amd as w
+    from wave_fenics_amd.distributed import VectorUpdater, overlapped_apply
+    p, n = 4, (3, 4, 13)
+    part, om, l2g = periodic_setup(oracle, n, p, (True, True, True), 0.15)
+    vu = VectorUpdater(part, device=gpu, comm=comm)
+    owned = part.owned_mask()
+    Kref = oracle.StiffnessOperator(om, p)
+    xg = np.random.default_rng(12).uniform(-1, 1, om.ndofs)
+    yg = np.zeros(om.ndofs)
+    Kref(xg, yg)
+    monkeypatch.setenv("WF_MARCH_LZ", str(lz))
+    monkeypatch.setenv("WF_MARCH_LZ0", str(lz0))
+    part.V.structured = True
+    K = w.StiffnessOperator(part.V, p, {"c0": 1500.0})
+    x = torch.from_numpy(np.where(owned, xg[l2g], 0.0)).to(gpu)
+    y = torch.zeros_like(x)
+    assert K.set_ghost_faces(*[bool(v) for v in part.owned_lo])
+    overlapped_apply(K, vu, x, y)
+    torch.cuda.synchronize()
+    assert relerr(y.cpu().numpy()[owned], yg[l2g[owned]]) <= 1e-12
+    # the parts together are the whole operator, whatever the segmentation
+    y2 = torch.zeros_like(x)
+    K(x, y2)      # unsplit apply (uniform segments) on the halo-updated x
+    vu.update_rev(y2)
+    torch.cuda.synchronize()
+    assert relerr(y2.cpu().numpy()[owned], yg[l2g[owned]]) <= 1e-12
+
+
 def test_periodic_rk4_vs_oracle(gpu, comm, oracle):
     """Full RK4 loop with the native exchange every stage (cfg4's code path on one
     GPU): source on x = lo, absorbing x = hi, periodic in y and z."""
