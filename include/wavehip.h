@@ -137,6 +137,43 @@ typedef enum {
                               diagonal y += m .* x (m = M 1 built once at create)  */
 } wf_flags;
 
+/* Which kernel an operator runs (wf_op_info_t.kernel) ... */
+typedef enum {
+  WF_KERNEL_NONE = 0,
+  WF_KERNEL_MARCH_BOX = 1,      /* k_stiffness_march: box mesh, implicit dofmap (stiffness_march.hip)       */
+  WF_KERNEL_MARCH_IDX = 2,      /* k_march_idx: lattice columns of any dofmap (stiffness_march_idx.hip)     */
+  WF_KERNEL_BATCH_UNIQUE = 3,   /* k_stiffness_generic_u / k_mass_lumped_u / k_mass_dense_col: batches of
+                                   cells with a unique-dof tile -- what a mesh that does not tile gets     */
+  WF_KERNEL_BOX_BLOCK = 4,      /* k_stiffness_box: one block of cells per workgroup, single pass           */
+  WF_KERNEL_DIAGONAL = 5,       /* pre-assembled lumped mass, y += m .* x                                   */
+  WF_KERNEL_MASS_DENSE_ANY = 6, /* k_mass_dense: any tensor rule (nq1 != P+1 allowed)                       */
+  WF_KERNEL_DENSE_SIMPLEX = 7,  /* k_stiffness_dense: MFMA fp64, affine simplices                           */
+  WF_KERNEL_ELEMENTWISE = 8     /* k_mass_lumped: one thread per element-local dof                          */
+} wf_kernel_id;
+
+/* ... and the explicit, thread-safe way to select one (tests, tuning runs).  Every field 0 =
+ * the library's own choice; a NULL wf_tuning* means all defaults.  The library reads no
+ * environment variable when it creates or applies an operator. */
+typedef enum {
+  WF_KERNEL_AUTO = 0,
+  WF_KERNEL_FORCE_BATCH = 1,      /* skip the lattice-column plan: the batch kernels                        */
+  WF_KERNEL_FORCE_BOX_BLOCK = 2,  /* box stiffness: the single-pass block kernel instead of marching        */
+  WF_KERNEL_FORCE_MASS_ANY = 3,   /* dense mass: the any-rule kernel even for square tables                 */
+  WF_KERNEL_FORCE_ELEMENTWISE = 4,/* batch kernels without the unique-dof tile (element-wise atomics)       */
+  WF_KERNEL_FORCE_MARCH = 5       /* adopt the lattice-column plan whatever its fill (default: plans whose
+                                     columns are mostly empty keep the batch kernel)                        */
+} wf_kernel_hint;
+typedef struct {
+  int kernel;        /* wf_kernel_hint                                                              */
+  int variant;       /* box marching kernel: compiled column cross-section + 1 (0 = default)        */
+  int lz;            /* layers per z segment of the marching kernels (0 = chosen from the mesh)     */
+  int lz0;           /* length of the first z segment under a z ghost plane (0 = 3)                 */
+  int bx, by, bz;    /* cells per block of the single-pass box kernel (0 = default)                 */
+  int keep_cell_order; /* batch kernels: do not sort the cells by their smallest dof                */
+  int orient;        /* lattice plan: 0 = normalise cell orientations (default), 1 = require the
+                        cells to agree as given                                                     */
+} wf_tuning;
+
 typedef struct {
   int kind;                    /* wf_op_kind                                    */
   int degree;                  /* P in 1..7, hexahedron, nd = (P+1)^3           */
@@ -163,6 +200,7 @@ typedef struct {
    * [nq1]) at which det J * w is computed on the device (mass.hpp:35-39).        */
   const double* h_qpts1;
   const double* h_qwts1;
+  const wf_tuning* tuning;     /* NULL = defaults                                */
 } wf_op_desc;
 
 /* Op(V, degree[, params]) constructors: operators.hpp:53,149; mass.hpp:20;
@@ -176,6 +214,8 @@ int wf_op_create(const wf_op_desc* desc, wf_op** out);
  * h_xverts [(nx+1)(ny+1)(nz+1)][3]. */
 int wf_op_create_box(int kind, int degree, int nx, int ny, int nz,
                      const double* h_xverts, double c0, int flags, wf_op** out);
+int wf_op_create_box_tuned(int kind, int degree, int nx, int ny, int nz, const double* h_xverts, double c0, int flags,
+                           const wf_tuning* tuning, wf_op** out);
 
 /* Dense (non-tensor-product) stiffness operator on affine simplex cells: the
  * reference's skernel (common/operators.hpp:113-133) fed with arbitrary dense
@@ -203,19 +243,27 @@ int wf_op_create_dense_simplex(const wf_dense_desc* desc, wf_op** out);
  * spectral_mass.hpp:84. */
 int wf_op_apply(wf_op* op, const double* d_x, double* d_y, void* stream);
 
-/* Interior / interface split of a box stiffness operator on a domain-decomposed
- * mesh: lets the caller overlap the forward ghost update
- * (VectorUpdater::update_fwd_begin/_end, demo/gpu_scatter_mpi/VectorUpdater.hpp:106-143)
- * with the cells that read no ghost value.  ghost_*0 != 0 marks the lower lattice
- * plane of that axis as a ghost plane.  apply(INTERIOR) + apply(INTERFACE) == apply. */
+/* Interior / interface split of a stiffness operator on a domain-decomposed mesh: lets the
+ * caller overlap the ghost updates (VectorUpdater::update_fwd_begin/_end and update_rev,
+ * demo/gpu_scatter_mpi/VectorUpdater.hpp:106-143,157-199) with the work that touches no ghost
+ * dof.  The operator's work items (columns of cells, stiffness_march*.hip) are sorted into
+ * INTERFACE (the item's dof tile contains a ghost position) and INTERIOR;
+ * apply(INTERIOR) + apply(INTERFACE) == apply.
+ *   wf_op_set_ghost_dofs : any marching operator (box or arbitrary dofmap), ghosts given as
+ *                          positions in the local array -- the same list the updater gets
+ *                          (wf_updater_desc.ghost_positions, any order, duplicates allowed);
+ *   wf_op_set_ghost_faces: box operators, ghosts = the lower lattice plane of the marked axes
+ *                          (the Cartesian partition of SURVEY 8e).
+ * WF_ERR_UNSUPPORTED for operators that run a batch kernel (no work items to sort). */
 typedef enum {
   WF_PART_ALL = 0,
-  WF_PART_INTERIOR = 1,    /* every cell that reads no ghost value                       */
+  WF_PART_INTERIOR = 1,    /* every work item that touches no ghost dof                   */
   WF_PART_INTERFACE = 2,
   WF_PART_INTERIOR_A = 3,  /* INTERIOR split in two halves: A hides the forward halo,    */
   WF_PART_INTERIOR_B = 4   /* B the reverse (add) halo; A + B == INTERIOR                */
 } wf_part;
 int wf_op_set_ghost_faces(wf_op* op, int ghost_x0, int ghost_y0, int ghost_z0);
+int wf_op_set_ghost_dofs(wf_op* op, const int32_t* h_ghost_positions, int32_t nghosts);
 int wf_op_apply_part(wf_op* op, const double* d_x, double* d_y, int part, void* stream);
 
 typedef struct {
@@ -223,7 +271,12 @@ typedef struct {
   double flops;          /* reference model 4*ncells*nq*nd (mass.hpp:71)        */
   double alg_bytes;      /* algorithmic HBM bytes per apply          */
   size_t device_bytes;   /* device memory owned by the operator                  */
-  int items_interior, items_interface; /* work items per part (wf_op_set_ghost_faces) */
+  int items_interior, items_interface; /* work items per part (wf_op_set_ghost_*)     */
+  int kernel;            /* wf_kernel_id: the kernel wf_op_apply launches               */
+  int plan_items, plan_patterns, plan_lz; /* lattice-column plan (WF_KERNEL_MARCH_IDX): work items,
+                            distinct index tables, layers per item; 0 otherwise          */
+  int plan_reoriented;   /* cells whose local axes the plan rotated / reflected to make them agree */
+  double plan_fill;      /* cells / cell slots of the plan's columns                     */
 } wf_op_info_t;
 int wf_op_info(const wf_op* op, wf_op_info_t* info); /* num_quads()/num_cells()/... mass.hpp:68-71 */
 int wf_op_destroy(wf_op* op);
@@ -293,6 +346,7 @@ typedef enum { WF_SUM = 0, WF_MAX = 1 } wf_reduce_op;
 int wf_comm_unique_id(char* id /* [WF_COMM_ID_BYTES] */);
 int wf_comm_create(const char* id, int rank, int nranks, wf_comm** out);
 /* rank 0 publishes the id in `path` (unique per job), the others poll up to timeout_s */
+int wf_comm_rendezvous_file(const char* path, int rank, double timeout_s, char* id /* [WF_COMM_ID_BYTES] */);
 int wf_comm_create_from_file(const char* path, int rank, int nranks, double timeout_s, wf_comm** out);
 int wf_comm_info(const wf_comm* comm, int* rank, int* nranks, int* rccl_version); /* outputs may be NULL */
 /* MPI_Allreduce of demo/gpu_cg/CUDA/cg.hpp:21 on device scalars / arrays (in place allowed) */
@@ -309,8 +363,10 @@ int wf_comm_destroy(wf_comm* comm);
  * be its own neighbour (periodic partition). */
 typedef enum {
   WF_UPDATER_DEFAULT = 0,
-  WF_UPDATER_INLINE = 1   /* enqueue the exchange on the caller's stream instead of the
+  WF_UPDATER_INLINE = 1,  /* enqueue the exchange on the caller's stream instead of the
                              updater's communication stream (begin/end then do not overlap) */
+  WF_UPDATER_CHAIN_ON_SIDE = 2 /* wf_op_apply_overlapped: halo chain on the updater's high-priority
+                             stream and the interior on the caller's (default: the reverse)   */
 } wf_updater_flags;
 typedef struct {
   int ndofs;                          /* local array length: owned + ghosts               */
@@ -339,10 +395,12 @@ int wf_updater_rev(wf_updater* u, double* d_x, void* stream);
 int wf_updater_info(const wf_updater* u, int* num_send, int* num_recv, int* num_send_neighbors, int* num_recv_neighbors);
 int wf_updater_destroy(wf_updater* u);
 
-/* y += A x on a domain-decomposed box mesh (LinearGLL.hpp:164-176 = scatter_fwd(x);
- * apply; scatter_rev(y)) with both halo directions hidden: the updater's side stream
- * runs update_fwd(x) -> apply(INTERFACE) -> update_rev(y) beside apply(INTERIOR) on
- * `stream`, which continues after both.  Needs wf_op_set_ghost_faces. */
+/* y += A x on a domain-decomposed mesh (LinearGLL.hpp:164-176 = scatter_fwd(x); apply;
+ * scatter_rev(y)) with both halo directions hidden: update_fwd(x) -> apply(INTERFACE) ->
+ * update_rev(y) runs on `stream` (the longer chain, so `stream` continues behind the reverse
+ * unpack with no cross-stream wait on its critical path), apply(INTERIOR) beside it on a
+ * low-priority stream of the updater; `stream` continues after both.
+ * Needs wf_op_set_ghost_dofs / wf_op_set_ghost_faces. */
 int wf_op_apply_overlapped(wf_op* op, wf_updater* u, double* d_x, double* d_y, void* stream);
 
 /* ---- 8f: matrix-free conjugate gradients (BP1) -----------------------------
@@ -387,6 +445,28 @@ int wf_mesh_close(wf_mesh_file* m);
 int wf_mesh_write(const char* xdmf_path, const char* grid_name, int64_t nverts, const double* h_xverts, int64_t ncells,
                   const int32_t* h_cells, const char* tags_name, int64_t nfacets, const int32_t* h_facet_verts,
                   const int32_t* h_values);
+
+/* ---- 8f: what DOLFINx derives from the mesh for the CPU demo (host only) ------------------
+ * demo/cpu_planar3d/main.cpp:39-66, common/LinearGLL.hpp:113-115.  Cells and facets in the
+ * engine's tensor vertex order (wf_mesh_read / wf_mesh_read_tags deliver it); cells may have ANY
+ * local orientation.
+ * wf_fs_build: fem::create_functionspace(mesh, Lagrange(hexahedron, degree, gll_warped)): dofs are
+ *   identified topologically (vertex / edge / face / interior entity + canonical position) and
+ *   numbered in lexicographic (z, y, x) order of their coordinates.  h_dofmap [ncells][(P+1)^3],
+ *   tensor order of each cell's own frame; h_dof_coords [coords_capacity >= *ndofs][3] may be NULL.
+ * wf_fs_locate_facets: (cell, axis, side) of facets given by their four vertices (meshtags).
+ * wf_fs_facet_mass: the tagged boundary dof set and its collocated facet masses
+ *   m[i] = sum_facets w_q |dx/ds x dx/dt| (diagonal GLL form of forms.ufl:19-24), ascending dofs;
+ *   h_idx / h_mass need capacity nfacets (P+1)^2.
+ * wf_fs_min_cell_diameter: min over cells of mesh::h (largest vertex distance), main.cpp:48-57. */
+int wf_fs_build(int degree, int64_t nverts, const double* h_xverts, int64_t ncells, const int32_t* h_cells,
+                int64_t* ndofs, int32_t* h_dofmap, double* h_dof_coords, int64_t coords_capacity);
+int wf_fs_locate_facets(int64_t ncells, const int32_t* h_cells, int64_t nfacets, const int32_t* h_facet_verts,
+                        int32_t* h_cell, int32_t* h_axis, int32_t* h_side);
+int wf_fs_facet_mass(int degree, int64_t nverts, const double* h_xverts, int64_t ncells, const int32_t* h_cells,
+                     const int32_t* h_dofmap, int64_t nfacets, const int32_t* h_cell, const int32_t* h_axis,
+                     const int32_t* h_side, int64_t* nout, int32_t* h_idx, double* h_mass);
+int wf_fs_min_cell_diameter(int64_t nverts, const double* h_xverts, int64_t ncells, const int32_t* h_cells, double* hmin);
 
 #ifdef __cplusplus
 }

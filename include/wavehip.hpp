@@ -243,6 +243,7 @@ public:
     d.h_phi1 = phi1.data();
     d.h_qpts1 = pts;
     d.h_qwts1 = wts;
+    d.flags |= WF_FLAG_NO_FABS;   // mass.hpp:35-39: det J * w keeps its sign (compute_jacobian_determinant)
     check(wf_op_create(&d, &_op));
   }
 };
@@ -352,6 +353,8 @@ public:
   ~VectorUpdater() { wf_updater_destroy(_u); }
 
   void update_fwd_begin(const T* x, void* stream = nullptr) { check(wf_updater_fwd_begin(_u, x, stream)); }
+  void update_fwd_begin(T* x, void* stream = nullptr) { update_fwd_begin(static_cast<const T*>(x), stream); }
+  void update_rev_begin(T* x, void* stream = nullptr) { update_rev_begin(static_cast<const T*>(x), stream); }
   void update_fwd_end(T* x, void* stream = nullptr) { check(wf_updater_fwd_end(_u, x, stream)); }
   void update_fwd(T* x, void* stream = nullptr) { check(wf_updater_fwd(_u, x, stream)); }
   void update_rev_begin(const T* x, void* stream = nullptr) { check(wf_updater_rev_begin(_u, x, stream)); }

@@ -93,12 +93,14 @@ def test_self_exchange_bit_exact(gpu, comm, oracle, periodic):
 @pytest.mark.parametrize("p,n,periodic,perturb", [(2, (4, 3, 3), (True, False, False), 0.2),
                                                   (4, (6, 3, 3), (True, True, False), 0.2),
                                                   (4, (3, 4, 12), (True, True, True), 0.15),
-                                                  (3, (3, 3, 4), (False, True, True), 0.2)])
+                                                  (3, (3, 3, 4), (False, True, True), 0.2),
+                                                  (6, (5, 2, 4), (True, True, True), 0.15)])
 def test_periodic_stiffness_vs_oracle(gpu, comm, oracle, p, n, periodic, perturb):
     """scatter_fwd(x); y += K x; scatter_rev(y) (LinearGLL.hpp:164-176) against the
-    oracle's stiffness operator on the periodic mesh: generic kernel, box kernel
-    (unsplit sequence) and wf_op_apply_overlapped (interior / interface split, the
-    exchanges on the updater's side stream)."""
+    oracle's stiffness operator on the periodic mesh: arbitrary-dofmap kernel and box kernel
+    (unsplit sequence), and wf_op_apply_overlapped (interior / interface split, both halo
+    directions hidden) for BOTH -- the box operator split by ghost faces, the arbitrary-dofmap
+    operator by ghost dofs (VectorUpdater.hpp:106-143,157-199 works on any IndexMap)."""
     import torch
     import wave_fenics_amd as w
     from wave_fenics_amd.distributed import VectorUpdater, overlapped_apply
@@ -110,13 +112,18 @@ def test_periodic_stiffness_vs_oracle(gpu, comm, oracle, p, n, periodic, perturb
     yg = np.zeros(om.ndofs)
     Kref(xg, yg)
     xl = np.where(owned, xg[l2g], 0.0)
-    for mode in ("generic", "box", "overlapped"):
-        part.V.structured = mode != "generic"
-        K = w.StiffnessOperator(part.V, p, {"c0": 1500.0})
+    for mode in ("generic", "box", "overlapped", "overlapped_generic"):
+        part.V.structured = mode in ("box", "overlapped")
+        K = w.StiffnessOperator(part.V, p, {"c0": 1500.0}, tuning={"kernel": "march"})
+        assert K.kernel == ("march_box" if part.V.structured else "march_idx")
         x = torch.from_numpy(xl).to(gpu)
         y = torch.zeros_like(x)
         if mode == "overlapped":
             assert K.set_ghost_faces(*[bool(v) for v in part.owned_lo])
+            overlapped_apply(K, vu, x, y)
+        elif mode == "overlapped_generic":
+            assert K.set_ghost_dofs(vu.h_ghost_pos)
+            assert K.info.items_interface > 0
             overlapped_apply(K, vu, x, y)
         else:
             vu.update_fwd(x)
@@ -128,7 +135,7 @@ def test_periodic_stiffness_vs_oracle(gpu, comm, oracle, p, n, periodic, perturb
 
 
 @pytest.mark.parametrize("lz,lz0", [(7, 2), (5, 1), (6, 6)])
-def test_overlapped_apply_short_first_segment(gpu, comm, oracle, monkeypatch, lz, lz0):
+def test_overlapped_apply_short_first_segment(gpu, comm, oracle, lz, lz0):
     """The split operator's z segmentation [0, lz0), then pieces of lz layers (the short first
     segment keeps the work that waits for the z halo small): wf_op_apply_overlapped on a fully
     periodic mesh with the segment lengths forced, against the oracle; lz0 = lz is the unsplit layout."""
@@ -143,10 +150,8 @@ def test_overlapped_apply_short_first_segment(gpu, comm, oracle, monkeypatch, lz
     xg = np.random.default_rng(12).uniform(-1, 1, om.ndofs)
     yg = np.zeros(om.ndofs)
     Kref(xg, yg)
-    monkeypatch.setenv("WF_MARCH_LZ", str(lz))
-    monkeypatch.setenv("WF_MARCH_LZ0", str(lz0))
     part.V.structured = True
-    K = w.StiffnessOperator(part.V, p, {"c0": 1500.0})
+    K = w.StiffnessOperator(part.V, p, {"c0": 1500.0}, tuning={"lz": lz, "lz0": lz0})
     x = torch.from_numpy(np.where(owned, xg[l2g], 0.0)).to(gpu)
     y = torch.zeros_like(x)
     assert K.set_ghost_faces(*[bool(v) for v in part.owned_lo])

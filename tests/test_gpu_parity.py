@@ -98,12 +98,11 @@ def test_stiffness_generic_permuted_dofmap(gpu, oracle):
                                        (4, (4, 4, 4), "1,1,1"), (2, (7, 5, 4), "3,3,3"), (3, (5, 4, 3), "4,2,2"),
                                        (1, (9, 5, 5), "4,4,4"), (5, (3, 2, 2), "7,1,1"), (6, (3, 2, 2), "5,1,1"),
                                        (7, (2, 2, 1), "2,2,1")])
-def test_stiffness_box_block_vs_oracle(gpu, oracle, p, n, block, monkeypatch):
+def test_stiffness_box_block_vs_oracle(gpu, oracle, p, n, block):
     """Structured (implicit dofmap) single-pass block kernel incl. partial blocks
-    at the mesh end."""
+    at the mesh end (selected through wf_tuning)."""
     import wave_fenics_amd as w
-    monkeypatch.setenv("WF_BOX_KERNEL", "block")
-    monkeypatch.setenv("WF_BOX_BLOCK", block)
+    tuning = {"kernel": "box_block", "block": tuple(int(v) for v in block.split(","))}
     om, mesh, V = make(oracle, n, p)
     K = oracle.StiffnessOperator(om, p)
     rng = np.random.default_rng(99)
@@ -111,8 +110,8 @@ def test_stiffness_box_block_vs_oracle(gpu, oracle, p, n, block, monkeypatch):
     y0 = rng.uniform(-1, 1, om.ndofs) * 1e6
     yref = y0.copy()
     K(x, yref)
-    op = w.StiffnessOperator(V, p, {"c0": 1500.0}, structured=True)
-    assert op.info.structured == 1
+    op = w.StiffnessOperator(V, p, {"c0": 1500.0}, structured=True, tuning=tuning)
+    assert op.info.structured == 1 and op.kernel == "box_block"
     y = dev(y0, gpu)
     op(dev(x, gpu), y)
     assert relerr(y.cpu().numpy(), yref) <= 1e-12
@@ -126,14 +125,11 @@ def test_stiffness_box_block_vs_oracle(gpu, oracle, p, n, block, monkeypatch):
     (5, (4, 3, 3), 0, 2), (5, (3, 3, 2), 1, 1), (5, (8, 2, 2), 2, 2),
     (6, (3, 3, 3), 0, 2), (6, (6, 2, 2), 1, 1), (6, (4, 2, 2), 2, 3),
     (7, (3, 3, 2), 0, 1), (7, (5, 2, 2), 1, 2), (7, (3, 2, 3), 2, 2)])
-def test_stiffness_march_vs_oracle(gpu, oracle, p, n, variant, lz, monkeypatch):
-    """The production box kernel (marching columns): every compiled column
-    cross-section, partial columns at the mesh end, z segments of 1..all layers,
-    accumulate semantics."""
+def test_stiffness_march_vs_oracle(gpu, oracle, p, n, variant, lz):
+    """The production box kernels (marching columns; the k-split form at P >= 5, which has one
+    cross-section per degree): every compiled column cross-section, partial columns at the mesh
+    end, z segments of 1..all layers, accumulate semantics."""
     import wave_fenics_amd as w
-    monkeypatch.setenv("WF_BOX_KERNEL", "march")
-    monkeypatch.setenv("WF_MARCH_VARIANT", str(variant))
-    monkeypatch.setenv("WF_MARCH_LZ", str(lz))
     om, mesh, V = make(oracle, n, p)
     K = oracle.StiffnessOperator(om, p)
     rng = np.random.default_rng(2024)
@@ -141,57 +137,67 @@ def test_stiffness_march_vs_oracle(gpu, oracle, p, n, variant, lz, monkeypatch):
     y0 = rng.uniform(-1, 1, om.ndofs) * 1e6
     yref = y0.copy()
     K(x, yref)
-    op = w.StiffnessOperator(V, p, {"c0": 1500.0}, structured=True)
+    op = w.StiffnessOperator(V, p, {"c0": 1500.0}, structured=True, tuning={"variant": variant, "lz": lz})
+    assert op.kernel == "march_box" and op.info.plan_lz == lz
     y = dev(y0, gpu)
     op(dev(x, gpu), y)
     assert relerr(y.cpu().numpy(), yref) <= 1e-12
     # default segmentation as well
-    monkeypatch.delenv("WF_MARCH_LZ")
-    op = w.StiffnessOperator(V, p, {"c0": 1500.0}, structured=True)
+    op = w.StiffnessOperator(V, p, {"c0": 1500.0}, structured=True, tuning={"variant": variant})
     y = dev(y0, gpu)
     op(dev(x, gpu), y)
     assert relerr(y.cpu().numpy(), yref) <= 1e-12
 
 
+@pytest.mark.parametrize("p,n", [(4, (11, 5, 6)), (6, (6, 2, 5))])
+@pytest.mark.parametrize("structured", [True, False])
 @pytest.mark.parametrize("ghost", [(1, 0, 0), (0, 1, 1), (1, 1, 1), (0, 0, 0)])
-def test_interior_interface_split(gpu, oracle, ghost, monkeypatch):
-    """apply(INTERIOR) + apply(INTERFACE) == apply, and the interior part reads
-    no ghost plane of x (poisoned with NaN)."""
+def test_interior_interface_split(gpu, oracle, ghost, structured, p, n):
+    """apply(INTERIOR) + apply(INTERFACE) == apply, and the interior part reads no ghost dof of x
+    (poisoned with NaN) -- for the box kernels (wf_op_set_ghost_faces and wf_op_set_ghost_dofs) and
+    for the arbitrary-dofmap marching kernels (wf_op_set_ghost_dofs: an item is interface iff its
+    dof tile contains a ghost position).  VectorUpdater.hpp:106-143,157-199."""
     import torch
     import wave_fenics_amd as w
-    from wave_fenics_amd._lib import WF_PART_INTERFACE, WF_PART_INTERIOR
-    monkeypatch.setenv("WF_MARCH_LZ", "2")
-    p, n = 4, (11, 5, 6)
+    from wave_fenics_amd._lib import WF_PART_INTERFACE, WF_PART_INTERIOR, WF_PART_INTERIOR_A, WF_PART_INTERIOR_B
     om, mesh, V = make(oracle, n, p)
-    op = w.StiffnessOperator(V, p, {"c0": 1500.0}, structured=True)
-    assert op.set_ghost_faces(*[bool(g) for g in ghost])
-    assert op.info.items_interior + op.info.items_interface > 0
+    NX, NY, NZ = V.lattice
+    lat = np.arange(om.ndofs).reshape(NZ, NY, NX)
+    gpos = np.concatenate([lat[:, :, 0].ravel() if ghost[0] else [], lat[:, 0, :].ravel() if ghost[1] else [],
+                           lat[0, :, :].ravel() if ghost[2] else []]).astype(np.int32)
     rng = np.random.default_rng(8)
     x = dev(rng.uniform(-1, 1, om.ndofs), gpu)
-    yall = torch.zeros_like(x)
-    op(x, yall)
-    ya = torch.zeros_like(x)
-    xp = x.clone().reshape(V.lattice[2], V.lattice[1], V.lattice[0])
-    if ghost[0]:
-        xp[:, :, 0] = float("nan")
-    if ghost[1]:
-        xp[:, 0, :] = float("nan")
-    if ghost[2]:
-        xp[0, :, :] = float("nan")
-    op.apply_part(xp.reshape(-1).contiguous(), ya, WF_PART_INTERIOR)
-    assert bool(torch.isfinite(ya).all()), "interior part read a ghost plane"
-    op.apply_part(x, ya, WF_PART_INTERFACE)
-    assert relerr(ya.cpu().numpy(), yall.cpu().numpy()) <= 1e-13
-    # the two interior halves (forward halo under A, reverse halo under B) add up to INTERIOR
-    from wave_fenics_amd._lib import WF_PART_INTERIOR_A, WF_PART_INTERIOR_B
-    yb = torch.zeros_like(x)
-    for part in (WF_PART_INTERIOR_A, WF_PART_INTERFACE, WF_PART_INTERIOR_B):
-        op.apply_part(x, yb, part)
-    assert relerr(yb.cpu().numpy(), yall.cpu().numpy()) <= 1e-13
-    if ghost == (0, 0, 0):
-        assert op.info.items_interface == 0
-    opg = w.StiffnessOperator(V, p, structured=False)
-    assert opg.set_ghost_faces(True, False, False) is False      # generic kernel: unsplit sequence
+    modes = ("faces", "dofs") if structured else ("dofs",)
+    for mode in modes:
+        op = w.StiffnessOperator(V, p, {"c0": 1500.0}, structured=structured, tuning={"lz": 2, "kernel": "march"})
+        assert op.kernel == ("march_box" if structured else "march_idx")
+        if mode == "faces":
+            assert op.set_ghost_faces(*[bool(g) for g in ghost])
+        else:
+            assert op.set_ghost_dofs(gpos)
+        assert op.info.items_interior + op.info.items_interface > 0
+        if any(ghost):
+            assert op.info.items_interface > 0 and op.info.items_interior > 0
+        yall = torch.zeros_like(x)
+        op(x, yall)
+        ya = torch.zeros_like(x)
+        xp = x.clone()
+        xp[torch.from_numpy(gpos.astype(np.int64)).to(gpu)] = float("nan")
+        op.apply_part(xp, ya, WF_PART_INTERIOR)
+        assert bool(torch.isfinite(ya).all()), "interior part read a ghost dof"
+        op.apply_part(x, ya, WF_PART_INTERFACE)
+        assert relerr(ya.cpu().numpy(), yall.cpu().numpy()) <= 1e-13
+        # the two interior halves (forward halo under A, reverse halo under B) add up to INTERIOR
+        yb = torch.zeros_like(x)
+        for part in (WF_PART_INTERIOR_A, WF_PART_INTERFACE, WF_PART_INTERIOR_B):
+            op.apply_part(x, yb, part)
+        assert relerr(yb.cpu().numpy(), yall.cpu().numpy()) <= 1e-13
+        if ghost == (0, 0, 0):
+            assert op.info.items_interface == 0
+    # an operator on a batch kernel has no work items to sort: the caller uses the unsplit sequence
+    opg = w.StiffnessOperator(V, p, structured=False, tuning={"kernel": "batch"})
+    assert opg.kernel == "batch_unique" and opg.set_ghost_dofs(gpos) is False
+    assert opg.set_ghost_faces(True, False, False) is False
 
 
 def test_geometry_vs_oracle(gpu, oracle):

@@ -16,6 +16,12 @@ class WavehipError(RuntimeError):
     (common/cuda/array.hpp:15-17, mass.hpp:91-92, utils.hpp:30-34)."""
 
 
+class Tuning(ctypes.Structure):
+    """wf_tuning: explicit kernel selection / tuning (all zero = the library's choice)."""
+    _fields_ = [("kernel", c_int), ("variant", c_int), ("lz", c_int), ("lz0", c_int),
+                ("bx", c_int), ("by", c_int), ("bz", c_int), ("keep_cell_order", c_int), ("orient", c_int)]
+
+
 class OpDesc(ctypes.Structure):
     _fields_ = [
         ("kind", c_int), ("degree", c_int), ("ncells", c_int), ("ndofs", c_int),
@@ -25,6 +31,7 @@ class OpDesc(ctypes.Structure):
         ("c0", c_double), ("flags", c_int),
         ("nq1", c_int), ("h_phi1", POINTER(c_double)),
         ("h_qpts1", POINTER(c_double)), ("h_qwts1", POINTER(c_double)),
+        ("tuning", POINTER(Tuning)),
     ]
 
 
@@ -43,6 +50,8 @@ class OpInfo(ctypes.Structure):
         ("num_quads", c_int), ("ndofs", c_int), ("structured", c_int),
         ("flops", c_double), ("alg_bytes", c_double), ("device_bytes", c_size_t),
         ("items_interior", c_int), ("items_interface", c_int),
+        ("kernel", c_int), ("plan_items", c_int), ("plan_patterns", c_int), ("plan_lz", c_int),
+        ("plan_reoriented", c_int), ("plan_fill", c_double),
     ]
 
 
@@ -72,7 +81,11 @@ WF_VARIANT_GLL_WARPED, WF_VARIANT_EQUISPACED = 0, 1
 WF_MAX_QUAD_POINTS = 16
 WF_COMM_ID_BYTES = 128
 WF_SUM, WF_MAX = 0, 1
-WF_UPDATER_DEFAULT, WF_UPDATER_INLINE = 0, 1
+WF_UPDATER_DEFAULT, WF_UPDATER_INLINE, WF_UPDATER_CHAIN_ON_SIDE = 0, 1, 2
+(WF_KERNEL_NONE, WF_KERNEL_MARCH_BOX, WF_KERNEL_MARCH_IDX, WF_KERNEL_BATCH_UNIQUE, WF_KERNEL_BOX_BLOCK, WF_KERNEL_DIAGONAL,
+ WF_KERNEL_MASS_DENSE_ANY, WF_KERNEL_DENSE_SIMPLEX, WF_KERNEL_ELEMENTWISE) = range(9)
+(WF_KERNEL_AUTO, WF_KERNEL_FORCE_BATCH, WF_KERNEL_FORCE_BOX_BLOCK, WF_KERNEL_FORCE_MASS_ANY, WF_KERNEL_FORCE_ELEMENTWISE,
+ WF_KERNEL_FORCE_MARCH) = range(6)
 WF_OP_STIFFNESS, WF_OP_MASS_LUMPED, WF_OP_MASS_DENSE = 0, 1, 2
 WF_FLAG_NONE, WF_FLAG_NO_FABS, WF_FLAG_NO_CLAMP, WF_FLAG_MASS_ELEMENTWISE, WF_FLAG_TENSOR_X_SLOWEST = 0, 1, 2, 4, 8
 WF_PART_ALL, WF_PART_INTERIOR, WF_PART_INTERFACE, WF_PART_INTERIOR_A, WF_PART_INTERIOR_B = 0, 1, 2, 3, 4
@@ -100,6 +113,9 @@ SIGNATURES = {
     "wf_geometry_hex": (c_int, [c_int, c_int, c_int, _dp, _ip, c_int, c_int, _dp, _dp]),
     "wf_op_create": (c_int, [POINTER(OpDesc), POINTER(c_void_p)]),
     "wf_op_create_box": (c_int, [c_int, c_int, c_int, c_int, c_int, _dp, c_double, c_int, POINTER(c_void_p)]),
+    "wf_op_create_box_tuned": (c_int, [c_int, c_int, c_int, c_int, c_int, _dp, c_double, c_int, POINTER(Tuning),
+                                       POINTER(c_void_p)]),
+    "wf_op_set_ghost_dofs": (c_int, [c_void_p, _ip, c_int32]),
     "wf_op_create_dense_simplex": (c_int, [POINTER(DenseDesc), POINTER(c_void_p)]),
     "wf_op_apply": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "wf_op_set_ghost_faces": (c_int, [c_void_p, c_int, c_int, c_int]),
@@ -121,6 +137,7 @@ SIGNATURES = {
     "wf_rk4_stage": (c_int, [c_int64, c_double, c_double, c_int] + [c_void_p] * 12),
     "wf_comm_unique_id": (c_int, [c_char_p]),
     "wf_comm_create": (c_int, [c_char_p, c_int, c_int, POINTER(c_void_p)]),
+    "wf_comm_rendezvous_file": (c_int, [c_char_p, c_int, c_double, c_char_p]),
     "wf_comm_create_from_file": (c_int, [c_char_p, c_int, c_int, c_double, POINTER(c_void_p)]),
     "wf_comm_info": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
     "wf_comm_allreduce": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_void_p, c_void_p]),
@@ -143,6 +160,10 @@ SIGNATURES = {
     "wf_mesh_read_tags": (c_int, [c_void_p, c_char_p, _ip, _ip]),
     "wf_mesh_close": (c_int, [c_void_p]),
     "wf_mesh_write": (c_int, [c_char_p, c_char_p, c_int64, _dp, c_int64, _ip, c_char_p, c_int64, _ip, _ip]),
+    "wf_fs_build": (c_int, [c_int, c_int64, _dp, c_int64, _ip, POINTER(c_int64), _ip, _dp, c_int64]),
+    "wf_fs_locate_facets": (c_int, [c_int64, _ip, c_int64, _ip, _ip, _ip, _ip]),
+    "wf_fs_facet_mass": (c_int, [c_int, c_int64, _dp, c_int64, _ip, _ip, c_int64, _ip, _ip, _ip, POINTER(c_int64), _ip, _dp]),
+    "wf_fs_min_cell_diameter": (c_int, [c_int64, _dp, c_int64, _ip, POINTER(c_double)]),
     "wf_cg": (c_int, [POINTER(CGDesc), c_void_p, c_void_p, POINTER(c_int), POINTER(c_double), c_void_p]),
     "wf_boundary_apply": (c_int, [c_int32, c_void_p, c_void_p, c_double, c_int32, c_void_p, c_void_p, c_double,
                                   c_void_p, c_void_p, c_void_p]),

@@ -37,6 +37,10 @@ struct wf_op {
   DenseOpData* dense = nullptr;   // dense simplex operator (stiffness_dense.hip)
   int dense_clamp = 1;
   size_t device_bytes = 0;
+  int kernel_id = WF_KERNEL_NONE;   // what wf_op_apply launches (wf_op_info_t.kernel)
+  int plan_reoriented = 0;
+  double plan_fill = 0.0;
+  wf_tuning tun{};
 };
 
 namespace {
@@ -137,7 +141,7 @@ int build_unique_lists(wf_op* op, size_t ncells, int nd, int CB)
   return WF_OK;
 }
 
-void default_box_block(int P, int* bx, int* by, int* bz)
+void default_box_block(int P, const wf_tuning& tun, int* bx, int* by, int* bz)
 {
   switch (P) {
     case 1: *bx = 4; *by = 4; *bz = 4; break;
@@ -148,15 +152,21 @@ void default_box_block(int P, int* bx, int* by, int* bz)
     case 6: *bx = 5; *by = 1; *bz = 1; break;
     default: *bx = 4; *by = 1; *bz = 1; break;
   }
-  // tuning hook: WF_BOX_BLOCK="bx,by,bz"
-  if (const char* e = std::getenv("WF_BOX_BLOCK")) {
-    int a, b, c;
-    if (std::sscanf(e, "%d,%d,%d", &a, &b, &c) == 3 && a > 0 && b > 0 && c > 0
-        && a * b * c * (P + 1) * (P + 1) <= 256) {
-      *bx = a;
-      *by = b;
-      *bz = c;
-    }
+  if (tun.bx > 0 && tun.by > 0 && tun.bz > 0 && tun.bx * tun.by * tun.bz * (P + 1) * (P + 1) <= 256) {
+    *bx = tun.bx;
+    *by = tun.by;
+    *bz = tun.bz;
+  }
+}
+
+// kernel the batch path runs for each operator kind (wf_op_info_t.kernel)
+int batch_kernel_id(const wf_op* op)
+{
+  switch (op->kind) {
+    case WF_OP_STIFFNESS: return op->generic_unique ? WF_KERNEL_BATCH_UNIQUE : WF_KERNEL_ELEMENTWISE;
+    case WF_OP_MASS_LUMPED:
+      return op->d_mdiag ? WF_KERNEL_DIAGONAL : (op->generic_unique ? WF_KERNEL_BATCH_UNIQUE : WF_KERNEL_ELEMENTWISE);
+    default: return (op->dense_square && op->generic_unique) ? WF_KERNEL_BATCH_UNIQUE : WF_KERNEL_MASS_DENSE_ANY;
   }
 }
 
@@ -370,46 +380,81 @@ int wf_op_create(const wf_op_desc* desc, wf_op** out)
   op->ncells = desc->ncells;
   op->ndofs = desc->ndofs;
   op->coeff = -1.0 * desc->c0 * desc->c0;   // operators.hpp:115
+  const wf_tuning tun = desc->tuning ? *desc->tuning : wf_tuning{};
+  op->tun = tun;
+  const bool force_batch = tun.kernel == WF_KERNEL_FORCE_BATCH || tun.kernel == WF_KERNEL_FORCE_ELEMENTWISE
+                           || tun.kernel == WF_KERNEL_FORCE_MASS_ANY;
+  const bool no_unique = tun.kernel == WF_KERNEL_FORCE_ELEMENTWISE;
   int rc;
 
-  // ---- stiffness, default path: indexed marching over lattice columns (generic_plan.cpp) ----
-  {
-    const char* gk = std::getenv("WF_GENERIC");
-    const bool legacy = gk && (std::strcmp(gk, "flat") == 0 || std::strcmp(gk, "u") == 0);
-    // P >= 5: two geometry register sets do not fit 256 VGPRs; a single set refilled level by level
-    // ("rolling") compiles to 256 VGPRs + spills and measured slower than the batch kernel
-    // (10.2 M dofs: P5 0.288 vs 0.272 ms, P6 0.367 vs 0.261 ms, P7 0.526 vs 0.293 ms) -- batch kernel there
-    if (desc->kind == WF_OP_STIFFNESS && !legacy && P <= 4 && ncells > 0) {
+  // ---- default path of the stiffness operator and of the dense mass with a square 1-D table: marching
+  // over lattice columns found in the caller's mesh (generic_plan.cpp) --------------------------
+  const bool plan_stiffness = desc->kind == WF_OP_STIFFNESS;
+  const bool plan_mass = desc->kind == WF_OP_MASS_DENSE && desc->nq1 == n && desc->h_phi1
+                         && (desc->h_detJ || (have_mesh && desc->h_qpts1 && desc->h_qwts1));
+  if ((plan_stiffness || plan_mass) && !force_batch && ncells > 0) {
+    if (plan_stiffness)
       WF_REQUIRE(desc->h_G || have_mesh, "wf_op_create: stiffness needs h_G or the mesh (h_xverts, h_geom_dofmap)");
-      // tensor-ordered dofmap in the caller's cell order (permute.hpp:10-27)
-      std::vector<int32_t> tdm;
-      const int32_t* tsrc = desc->h_dofmap;
-      if (use_perm) {
-        tdm.resize(ncells * nd);
-        if ((rc = wf_reorder_dofmap(desc->ncells, nd, use_perm, desc->h_dofmap, tdm.data())) != WF_OK) return rc;
-        tsrc = tdm.data();
-      }
-      static const int kBX[5] = {0, 8, 7, 4, 5}, kBY[5] = {0, 8, 4, 4, 2};   // BX * BY == cells_per_batch(P)
-      const int BX = kBX[P], BY = kBY[P], CB = BX * BY;
-      // layers per work item: as many as leave two workgroups per CU (80 KB of LDS each), at most 12
-      int lz_max = 16, lz_fixed = 0;
-      while (lz_max > 1 && march_idx_lds_bytes(P, BX, BY, lz_max) > (size_t)80 * 1024) --lz_max;
-      if (const char* e = std::getenv("WF_MARCH_LZ")) lz_fixed = std::max(1, std::atoi(e));
-      MarchPlan plan;
-      if ((rc = build_march_plan(P, ncells, tsrc, BX, BY, lz_max, lz_fixed, &plan)) != WF_OK) return rc;
-      if (plan.ok) {
-        const int lz = plan.lz;
-        const size_t nslots = (size_t)plan.nitems * lz * CB;
-        op->plan.nitems = plan.nitems;
-        op->plan.lz = lz;
-        op->plan.tile_size = plan.tile_size;
-        op->plan_patterns = plan.npatterns;
-        if ((rc = dev_upload(&op->plan.d_item_base, plan.item_base.data(), plan.item_base.size(), &op->device_bytes)) != WF_OK) return rc;
-        if ((rc = dev_upload(&op->plan.d_item_pattern, plan.item_pattern.data(), plan.item_pattern.size(), &op->device_bytes)) != WF_OK) return rc;
-        if ((rc = dev_upload(&op->plan.d_item_layers, plan.item_layers.data(), plan.item_layers.size(), &op->device_bytes)) != WF_OK) return rc;
-        if ((rc = dev_upload(&op->plan.d_pat_off, plan.pat_off.data(), plan.pat_off.size(), &op->device_bytes)) != WF_OK) return rc;
-        op->have_plan = 1;
+    const int pkind = plan_stiffness ? OP_KIND_STIFFNESS : OP_KIND_MASS;
+    // tensor-ordered dofmap in the caller's cell order (permute.hpp:10-27)
+    std::vector<int32_t> tdm;
+    const int32_t* tsrc = desc->h_dofmap;
+    if (use_perm) {
+      tdm.resize(ncells * nd);
+      if ((rc = wf_reorder_dofmap(desc->ncells, nd, use_perm, desc->h_dofmap, tdm.data())) != WF_OK) return rc;
+      tsrc = tdm.data();
+    }
+    int BX, BY;
+    march_idx_shape(pkind, P, &BX, &BY);
+    const int CB = BX * BY, NTq = CB * n * n;
+    // layers per work item: as many as the kernel's LDS budget per workgroup allows, at most 16
+    int lz_max = 16;
+    while (lz_max > 1 && march_idx_lds_bytes(pkind, P, BX, BY, lz_max) > march_idx_lds_budget(pkind, P)) --lz_max;
+    const int use_fabs = (desc->flags & WF_FLAG_NO_FABS) ? 0 : 1;
+    const int clamp = (desc->flags & WF_FLAG_NO_CLAMP) ? 0 : 1;
+    // A cell may be looked at with an axis reversed only if the 1-D table reads the same backwards,
+    // phi1[n-1-q][n-1-a] == phi1[q][a] (true for every symmetric node / point set; the GLL derivative
+    // matrix of the stiffness operator has the matching antisymmetry by construction).
+    bool normalise = tun.orient == 0;
+    if (plan_mass)
+      for (int q = 0; q < n && normalise; ++q)
+        for (int a2 = 0; a2 < n; ++a2)
+          if (std::abs(desc->h_phi1[q * n + a2] - desc->h_phi1[(n - 1 - q) * n + (n - 1 - a2)]) > 1e-13) normalise = false;
+    MarchPlan plan;
+    if ((rc = build_march_plan(P, ncells, tsrc, BX, BY, lz_max, std::max(0, tun.lz), normalise, &plan)) != WF_OK) return rc;
+    // mostly empty columns (a mesh one cell wide, a mesh shattered into tiny lattice components): the
+    // marching kernel would read geometry for every slot -- batch kernel instead
+    if (plan.ok && plan.fill < kMinPlanFill && tun.kernel != WF_KERNEL_FORCE_MARCH) plan.ok = false;
+    if (plan.ok) {
+      const int lz = plan.lz;
+      const size_t nslots = (size_t)plan.nitems * lz * CB;
+      op->plan.nitems = plan.nitems;
+      op->plan.lz = lz;
+      op->plan.tile_size = plan.tile_size;
+      op->plan_patterns = plan.npatterns;
+      op->plan_reoriented = plan.reoriented;
+      op->plan_fill = plan.fill;
+      if ((rc = dev_upload(&op->plan.d_item_base, plan.item_base.data(), plan.item_base.size(), &op->device_bytes)) != WF_OK) return rc;
+      if ((rc = dev_upload(&op->plan.d_item_pattern, plan.item_pattern.data(), plan.item_pattern.size(), &op->device_bytes)) != WF_OK) return rc;
+      if ((rc = dev_upload(&op->plan.d_item_layers, plan.item_layers.data(), plan.item_layers.size(), &op->device_bytes)) != WF_OK) return rc;
+      if ((rc = dev_upload(&op->plan.d_pat_off, plan.pat_off.data(), plan.pat_off.size(), &op->device_bytes)) != WF_OK) return rc;
+      op->kernel_id = WF_KERNEL_MARCH_IDX;
+      // engine point index (lattice frame of the cell, x fastest) -> the caller's point index, per orientation
+      std::vector<std::vector<int32_t>> pmaps(48);
+      auto point_map = [&](int code) -> const std::vector<int32_t>& {
+        auto& m = pmaps[code];
+        if (m.empty()) {
+          const std::vector<int32_t> qm = make_qmap(n);
+          m.resize(nd);
+          for (int k = 0; k < n; ++k)
+            for (int j = 0; j < n; ++j)
+              for (int i = 0; i < n; ++i) m[i + n * (j + n * k)] = qm[orient_local_index(code, n, i, j, k)];
+        }
+        return m;
+      };
 
+      if (plan_stiffness) {
+        op->have_plan = 1;
         std::vector<double> D(n * n);
         gll_derivative_matrix(P, D.data());
         for (int q = 0; q < n * n; ++q) op->dm.v[q] = D[q];
@@ -419,10 +464,10 @@ int wf_op_create(const wf_op_desc* desc, wf_op** out)
         const size_t g6 = nslots * nd * 6;
         if ((rc = dev_alloc(&op->d_G6blk, g6, &op->device_bytes)) != WF_OK) return rc;
         WF_HIP_CHECK(hipMemset(op->d_G6blk, 0, g6 * sizeof(double)));
-        const int use_fabs = (desc->flags & WF_FLAG_NO_FABS) ? 0 : 1;
-        const int clamp = (desc->flags & WF_FLAG_NO_CLAMP) ? 0 : 1;
         if (desc->h_G) {
-          const std::vector<int32_t> qm = make_qmap(n);
+          // G of a cell seen in the lattice frame: G'[a][b] = s_a s_b G[r_a][r_b] (r = the cell's own axis
+          // along lattice axis a, s = -1 when reversed) at the relabelled point -- the operator
+          // D^T G D is the same in every frame
           const size_t slab_slots = std::max<size_t>(CB, (((size_t)64 << 20) / (nd * 9 * sizeof(double))) / CB * CB);
           Scratch<double> d_G9;
           if ((rc = dev_alloc(&d_G9.p, std::min(slab_slots, nslots) * nd * 9, nullptr)) != WF_OK) return rc;
@@ -433,75 +478,64 @@ int wf_op_create(const wf_op_desc* desc, wf_op** out)
             for (size_t q = 0; q < ns; ++q) {
               const int32_t c = plan.slot_cell[s0 + q];
               if (c < 0) continue;
+              const int code = plan.cell_orient[c];
+              const std::vector<int32_t>& pm = point_map(code);
               const double* gsrc = desc->h_G + (size_t)c * nd * 9;
-              for (int pt = 0; pt < nd; ++pt) std::memcpy(&slab[(q * nd + pt) * 9], gsrc + (size_t)qm[pt] * 9, 9 * sizeof(double));
+              if (code == 0) {
+                for (int pt = 0; pt < nd; ++pt) std::memcpy(&slab[(q * nd + pt) * 9], gsrc + (size_t)pm[pt] * 9, 9 * sizeof(double));
+              } else {
+                int ra[3], fl[3];
+                orient_decode(code, ra, fl);
+                for (int pt = 0; pt < nd; ++pt) {
+                  const double* g9 = gsrc + (size_t)pm[pt] * 9;
+                  double* dst = &slab[(q * nd + pt) * 9];
+                  for (int a = 0; a < 3; ++a)
+                    for (int b2 = 0; b2 < 3; ++b2) dst[a * 3 + b2] = ((fl[a] ^ fl[b2]) ? -1.0 : 1.0) * g9[ra[a] * 3 + ra[b2]];
+                }
+              }
             }
             WF_HIP_CHECK(hipMemcpy(d_G9.p, slab.data(), ns * nd * 9 * sizeof(double), hipMemcpyHostToDevice));
-            if ((rc = launch_pack_G6(P, (int)ns, d_G9.p, op->d_G6blk + (s0 / CB) * CB * nd * 6, nullptr)) != WF_OK) return rc;
+            if ((rc = launch_pack_G6(P, CB, (int)ns, d_G9.p, op->d_G6blk + (s0 / CB) * CB * nd * 6, nullptr)) != WF_OK) return rc;
             WF_HIP_CHECK(hipDeviceSynchronize());
           }
         } else {
-          // one geometry thread per (present cell, point), written to the cell's slot
+          // one geometry thread per (present cell, point), written to the cell's slot; a cell is handed
+          // over with its vertices relabelled into the lattice frame
           std::vector<int32_t> gd, slot_of;
+          std::vector<uint8_t> sign;
           gd.reserve(ncells * 8);
           slot_of.reserve(ncells);
+          sign.reserve(ncells);
           for (size_t q = 0; q < nslots; ++q) {
             const int32_t c = plan.slot_cell[q];
             if (c < 0) continue;
-            gd.insert(gd.end(), desc->h_geom_dofmap + (size_t)c * 8, desc->h_geom_dofmap + (size_t)(c + 1) * 8);
+            const int code = plan.cell_orient[c];
+            const int32_t* gsrc = desc->h_geom_dofmap + (size_t)c * 8;
+            for (int v = 0; v < 8; ++v) gd.push_back(gsrc[orient_local_index(code, 2, v & 1, (v >> 1) & 1, (v >> 2) & 1)]);
             slot_of.push_back((int32_t)q);
+            sign.push_back((uint8_t)(int8_t)orient_sign(code));
           }
           Scratch<double> d_x, d_pts, d_wts;
           Scratch<int32_t> d_gd, d_slot;
+          Scratch<uint8_t> d_sign;
           if ((rc = dev_upload(&d_x.p, desc->h_xverts, (size_t)desc->nverts * 3, nullptr)) != WF_OK) return rc;
           if ((rc = dev_upload(&d_gd.p, gd.data(), gd.size(), nullptr)) != WF_OK) return rc;
           if ((rc = dev_upload(&d_slot.p, slot_of.data(), slot_of.size(), nullptr)) != WF_OK) return rc;
+          if ((rc = dev_upload(&d_sign.p, sign.data(), sign.size(), nullptr)) != WF_OK) return rc;
           if ((rc = upload_tables(P, d_pts, d_wts)) != WF_OK) return rc;
-          if ((rc = launch_geometry_hex_slots(P, (int)slot_of.size(), d_x.p, d_gd.p, d_slot.p, d_pts.p, d_wts.p, use_fabs, clamp,
-                                              op->d_G6blk, nullptr)) != WF_OK)
+          if ((rc = launch_geometry_hex_slots(P, CB, (int)slot_of.size(), d_x.p, d_gd.p, d_slot.p, d_sign.p, d_pts.p, d_wts.p,
+                                              use_fabs, clamp, op->d_G6blk, nullptr)) != WF_OK)
             return rc;
         }
-        WF_HIP_CHECK(hipDeviceSynchronize());
-        *out = op.release();
-        return WF_OK;
-      }
-      // the mesh does not tile into lattice columns: batch kernel below
-    }
-  }
-
-  // ---- dense mass with a square 1-D table: the same lattice columns, mass_column per layer ----
-  {
-    const char* gk = std::getenv("WF_GENERIC");
-    const bool legacy = gk && (std::strcmp(gk, "flat") == 0 || std::strcmp(gk, "u") == 0);
-    if (desc->kind == WF_OP_MASS_DENSE && !legacy && ncells > 0 && desc->nq1 == n && desc->h_phi1
-        && (desc->h_detJ || (have_mesh && desc->h_qpts1 && desc->h_qwts1)) && !std::getenv("WF_MASS_DENSE_GENERIC")) {
-      std::vector<int32_t> tdm;
-      const int32_t* tsrc = desc->h_dofmap;
-      if (use_perm) {
-        tdm.resize(ncells * nd);
-        if ((rc = wf_reorder_dofmap(desc->ncells, nd, use_perm, desc->h_dofmap, tdm.data())) != WF_OK) return rc;
-        tsrc = tdm.data();
-      }
-      static const int kBX[8] = {0, 8, 7, 4, 5, 7, 5, 2}, kBY[8] = {0, 8, 4, 4, 2, 1, 1, 2};
-      const int BX = kBX[P], BY = kBY[P], CB = BX * BY, NTq = CB * n * n;
-      int lz_max = 16, lz_fixed = 0;
-      while (lz_max > 1 && march_idx_lds_bytes(P, BX, BY, lz_max) > (size_t)80 * 1024) --lz_max;
-      if (const char* e = std::getenv("WF_MARCH_LZ")) lz_fixed = std::max(1, std::atoi(e));
-      MarchPlan plan;
-      if ((rc = build_march_plan(P, ncells, tsrc, BX, BY, lz_max, lz_fixed, &plan)) != WF_OK) return rc;
-      if (plan.ok) {
-        const int lz = plan.lz;
-        const size_t nslots = (size_t)plan.nitems * lz * CB;
-        // det J * w per cell and point, host copy in the caller's cell order and the engine's point order
-        std::vector<double> hd(ncells * nd);
-        if (desc->h_detJ) {
-          const std::vector<int32_t> qm = make_qmap(n);
-          for (size_t c = 0; c < ncells; ++c)
-            for (int q = 0; q < nd; ++q) hd[c * nd + q] = desc->h_detJ[c * nd + qm[q]];
-        } else {
+      } else {
+        // det J * w per cell and point, host copy in the caller's cell order and point order
+        std::vector<double> hd;
+        const double* hsrc = desc->h_detJ;
+        bool raw_points = false;   // hd is in the engine's (raw cell frame) point order already
+        if (!desc->h_detJ) {
           Scratch<double> d_x, d_qp, d_qw, d_det;
           Scratch<int32_t> d_gd;
-          const int use_fabs = (desc->flags & WF_FLAG_NO_FABS) ? 0 : 1;
+          hd.resize(ncells * nd);
           if ((rc = dev_upload(&d_x.p, desc->h_xverts, (size_t)desc->nverts * 3, nullptr)) != WF_OK) return rc;
           if ((rc = dev_upload(&d_gd.p, desc->h_geom_dofmap, ncells * 8, nullptr)) != WF_OK) return rc;
           if ((rc = dev_upload(&d_qp.p, desc->h_qpts1, (size_t)n, nullptr)) != WF_OK) return rc;
@@ -512,46 +546,48 @@ int wf_op_create(const wf_op_desc* desc, wf_op** out)
             return rc;
           WF_HIP_CHECK(hipDeviceSynchronize());
           WF_HIP_CHECK(hipMemcpy(hd.data(), d_det.p, hd.size() * sizeof(double), hipMemcpyDeviceToHost));
+          hsrc = hd.data();
+          raw_points = true;
         }
         // blocked slot layout [item * lz + layer][k][t], t = slot_in_layer * n^2 + j n + i; empty slots zero
         std::vector<double> blk(nslots * nd, 0.0);
         for (size_t q = 0; q < nslots; ++q) {
           const int32_t c = plan.slot_cell[q];
           if (c < 0) continue;
+          const int code = plan.cell_orient[c];
           const size_t sub = q / CB, sl = q % CB;
+          const double* src = hsrc + (size_t)c * nd;
           for (int k = 0; k < n; ++k)
-            std::memcpy(&blk[(sub * n + k) * NTq + sl * n * n], &hd[(size_t)c * nd + (size_t)k * n * n], (size_t)n * n * sizeof(double));
+            for (int ji = 0; ji < n * n; ++ji) {
+              const int l = ji + n * n * k;
+              const int rp = raw_points ? orient_local_index(code, n, l % n, (l / n) % n, l / (n * n)) : point_map(code)[l];
+              blk[(sub * n + k) * NTq + sl * n * n + ji] = src[rp];
+            }
         }
+        // A non-symmetric 1-D table kept the caller's frames (normalise above).
         if ((rc = dev_upload(&op->d_detJ, blk.data(), blk.size(), &op->device_bytes)) != WF_OK) return rc;
         if ((rc = dev_upload(&op->d_phi1, desc->h_phi1, (size_t)n * n, &op->device_bytes)) != WF_OK) return rc;
         for (int q = 0; q < n * n; ++q) op->dm.v[q] = desc->h_phi1[q];
-        op->plan.nitems = plan.nitems;
-        op->plan.lz = lz;
-        op->plan.tile_size = plan.tile_size;
-        op->plan_patterns = plan.npatterns;
-        if ((rc = dev_upload(&op->plan.d_item_base, plan.item_base.data(), plan.item_base.size(), &op->device_bytes)) != WF_OK) return rc;
-        if ((rc = dev_upload(&op->plan.d_item_pattern, plan.item_pattern.data(), plan.item_pattern.size(), &op->device_bytes)) != WF_OK) return rc;
-        if ((rc = dev_upload(&op->plan.d_item_layers, plan.item_layers.data(), plan.item_layers.size(), &op->device_bytes)) != WF_OK) return rc;
-        if ((rc = dev_upload(&op->plan.d_pat_off, plan.pat_off.data(), plan.pat_off.size(), &op->device_bytes)) != WF_OK) return rc;
         op->have_plan = 2;
         op->nq1 = n;
         op->nq = nd;
         op->dense_square = 1;
-        WF_HIP_CHECK(hipDeviceSynchronize());
-        *out = op.release();
-        return WF_OK;
       }
+      WF_HIP_CHECK(hipDeviceSynchronize());
+      *out = op.release();
+      return WF_OK;
     }
+    // the mesh does not tile into lattice columns: batch kernels below
   }
 
   // Internal cell order: cells are summed independently, so the operator may visit
   // them in any order.  Sorting by the smallest dof of each cell puts cells that
   // share dofs into the same workgroup batch whatever order the caller's mesh has
   // (a randomly ordered cfg2 mesh: 0.46 ms unsorted -> the 0.31 ms of the
-  // lexicographic order).  WF_NO_CELL_SORT=1 keeps the caller's order.
+  // lexicographic order).  wf_tuning.keep_cell_order keeps the caller's order.
   std::vector<int32_t> cperm(ncells);
   for (size_t c = 0; c < ncells; ++c) cperm[c] = (int32_t)c;
-  if (!std::getenv("WF_NO_CELL_SORT") && ncells > 1) {
+  if (!tun.keep_cell_order && ncells > 1) {
     std::vector<int32_t> key(ncells);
     for (size_t c = 0; c < ncells; ++c) key[c] = *std::min_element(desc->h_dofmap + c * nd, desc->h_dofmap + (c + 1) * nd);
     std::stable_sort(cperm.begin(), cperm.end(), [&](int32_t a, int32_t b) { return key[a] < key[b]; });
@@ -616,9 +652,8 @@ int wf_op_create(const wf_op_desc* desc, wf_op** out)
   if (desc->kind == WF_OP_STIFFNESS) {
     const int CB = cells_per_batch(P);
     const size_t nbatch = (ncells + CB - 1) / CB;
-    // batch-unique dof lists (WF_GENERIC=flat keeps the element-wise scatter for comparison)
-    const char* gk = std::getenv("WF_GENERIC");
-    if (!(gk && std::strcmp(gk, "flat") == 0) && (rc = build_unique_lists(op.get(), ncells, nd, CB)) != WF_OK) return rc;
+    // batch-unique dof lists (WF_KERNEL_FORCE_ELEMENTWISE keeps the element-wise scatter for comparison)
+    if (!no_unique && (rc = build_unique_lists(op.get(), ncells, nd, CB)) != WF_OK) return rc;
     const size_t g6 = nbatch * CB * nd * 6;
     if ((rc = dev_alloc(&op->d_G6blk, g6, &op->device_bytes)) != WF_OK) return rc;
     if (g6) WF_HIP_CHECK(hipMemset(op->d_G6blk, 0, g6 * sizeof(double)));
@@ -643,7 +678,7 @@ int wf_op_create(const wf_op_desc* desc, wf_op** out)
         }
         WF_HIP_CHECK(hipMemcpy(d_G9.p, hsrc, nc * nd * 9 * sizeof(double), hipMemcpyHostToDevice));
         // slabs start on a batch boundary, so the packed destination is offset by whole batches
-        if ((rc = launch_pack_G6(P, (int)nc, d_G9.p, op->d_G6blk + (c0 / CB) * CB * nd * 6, nullptr)) != WF_OK) return rc;
+        if ((rc = launch_pack_G6(P, CB, (int)nc, d_G9.p, op->d_G6blk + (c0 / CB) * CB * nd * 6, nullptr)) != WF_OK) return rc;
         WF_HIP_CHECK(hipDeviceSynchronize());
       }
     } else if (have_mesh) {
@@ -667,10 +702,9 @@ int wf_op_create(const wf_op_desc* desc, wf_op** out)
     op->nq1 = nq1;
     op->nq = nq1 * nq1 * nq1;
     {
-      const char* gk = std::getenv("WF_GENERIC");
       const int mx = std::max(n, nq1);
       // square tables (nq1 == P+1): column-thread kernel, batches of cells_per_batch(P)
-      const bool square = desc->kind == WF_OP_MASS_DENSE && nq1 == n && !std::getenv("WF_MASS_DENSE_GENERIC");
+      const bool square = desc->kind == WF_OP_MASS_DENSE && nq1 == n && tun.kernel != WF_KERNEL_FORCE_MASS_ANY;
       op->dense_square = square ? 1 : 0;
       const int CBm = (desc->kind == WF_OP_MASS_DENSE && !square) ? mass_dense_cells_per_batch(mx) : cells_per_batch(P);
       // dense mass: the unique-dof tile pays off only for small elements (measured at 10 M dofs:
@@ -679,8 +713,7 @@ int wf_op_create(const wf_op_desc* desc, wf_op** out)
       // reference's element-wise sequence
       const bool elementwise = desc->kind == WF_OP_MASS_LUMPED && (desc->flags & WF_FLAG_MASS_ELEMENTWISE);
       const bool want = elementwise || (desc->kind == WF_OP_MASS_DENSE && (P <= 3 || square));
-      if (want && !(gk && std::strcmp(gk, "flat") == 0) && (rc = build_unique_lists(op.get(), ncells, nd, CBm)) != WF_OK)
-        return rc;
+      if (want && !no_unique && (rc = build_unique_lists(op.get(), ncells, nd, CBm)) != WF_OK) return rc;
     }
     if (desc->h_detJ) {
       if ((rc = dev_upload(&op->d_detJ, h_detJ, ncells * op->nq, &op->device_bytes)) != WF_OK) return rc;
@@ -723,12 +756,19 @@ int wf_op_create(const wf_op_desc* desc, wf_op** out)
     }
   }
   WF_HIP_CHECK(hipDeviceSynchronize());
+  op->kernel_id = batch_kernel_id(op.get());
   *out = op.release();
   return WF_OK;
 }
 
 int wf_op_create_box(int kind, int degree, int nx, int ny, int nz, const double* h_xverts, double c0, int flags,
                      wf_op** out)
+{
+  return wf_op_create_box_tuned(kind, degree, nx, ny, nz, h_xverts, c0, flags, nullptr, out);
+}
+
+int wf_op_create_box_tuned(int kind, int degree, int nx, int ny, int nz, const double* h_xverts, double c0, int flags,
+                           const wf_tuning* tuning, wf_op** out)
 {
   WF_REQUIRE(out != nullptr, "wf_op_create_box: null output");
   *out = nullptr;
@@ -743,37 +783,7 @@ int wf_op_create_box(int kind, int degree, int nx, int ny, int nz, const double*
   WF_REQUIRE(NX * NY * NZ < ((size_t)1 << 31), "wf_op_create_box: dof lattice exceeds int32");
   const int n = P + 1, nd = n * n * n;
 
-  // P >= 5: the marching kernel has one wave per SIMD (two geometry register sets
-  // do not fit 256 VGPRs at two); the batch-unique generic kernel is faster there
-  // (P6, 10.2 M dofs: 0.29 ms vs 0.37 ms), so the box operator is built through the
-  // generic path with the lexicographic dofmap generated here.  WF_BOX_KERNEL overrides.
-  if (kind == WF_OP_STIFFNESS && P >= 5 && !std::getenv("WF_BOX_KERNEL")) {
-    const size_t ncell = (size_t)nx * ny * nz;
-    std::vector<int32_t> dm(ncell * nd), gd(ncell * 8);
-    for (int cz = 0; cz < nz; ++cz)
-      for (int cy = 0; cy < ny; ++cy)
-        for (int cx = 0; cx < nx; ++cx) {
-          const size_t c = cx + (size_t)nx * (cy + (size_t)ny * cz);
-          for (int v = 0; v < 8; ++v)
-            gd[c * 8 + v] = (int32_t)((cx + (v & 1)) + (size_t)(nx + 1) * ((cy + ((v >> 1) & 1)) + (size_t)(ny + 1) * (cz + ((v >> 2) & 1))));
-          for (int k = 0; k < n; ++k)
-            for (int j = 0; j < n; ++j)
-              for (int i = 0; i < n; ++i)
-                dm[c * nd + i + n * (j + n * k)] = (int32_t)((P * cx + i) + NX * ((P * cy + j) + NY * (size_t)(P * cz + k)));
-        }
-    wf_op_desc d{};
-    d.kind = WF_OP_STIFFNESS;
-    d.degree = P;
-    d.ncells = (int)ncell;
-    d.ndofs = (int)(NX * NY * NZ);
-    d.h_dofmap = dm.data();
-    d.nverts = (nx + 1) * (ny + 1) * (nz + 1);
-    d.h_xverts = h_xverts;
-    d.h_geom_dofmap = gd.data();
-    d.c0 = c0;
-    d.flags = flags;
-    return wf_op_create(&d, out);
-  }
+  const wf_tuning tun = tuning ? *tuning : wf_tuning{};
 
   std::unique_ptr<wf_op, void (*)(wf_op*)> op(new wf_op, free_op);
   op->kind = kind;
@@ -789,19 +799,23 @@ int wf_op_create_box(int kind, int degree, int nx, int ny, int nz, const double*
   op->ny = ny;
   op->nz = nz;
   op->coeff = -1.0 * c0 * c0;
-  default_box_block(P, &op->bx, &op->by, &op->bz);
+  op->tun = tun;
+  default_box_block(P, tun, &op->bx, &op->by, &op->bz);
+  op->kernel_id = WF_KERNEL_DIAGONAL;
   if (kind == WF_OP_STIFFNESS) {
-    // production kernel: marching columns (stiffness_march.hip).  Tuning hooks:
-    // WF_BOX_KERNEL=block selects the single-pass block kernel, WF_MARCH_VARIANT
-    // the compiled column cross-section, WF_MARCH_LZ the layers per z segment.
-    const char* kern = std::getenv("WF_BOX_KERNEL");
-    op->march = !(kern && std::strcmp(kern, "block") == 0);
+    // production kernel: marching columns (stiffness_march.hip; P >= 5: the k-split form,
+    // stiffness_march_ks.hip).  wf_tuning: kernel = WF_KERNEL_FORCE_BOX_BLOCK selects the single-pass
+    // block kernel, variant the compiled column cross-section, lz the layers per z segment.
+    op->march = tun.kernel != WF_KERNEL_FORCE_BOX_BLOCK;
+    op->kernel_id = op->march ? WF_KERNEL_MARCH_BOX : WF_KERNEL_BOX_BLOCK;
     if (op->march) {
-      const char* v = std::getenv("WF_MARCH_VARIANT");
       static const int kDefaultVariant[8] = {0, 0, 0, 0, 1, 0, 0, 0};   // P4: 5x2 columns (measured fastest)
-      op->march_variant = v ? std::atoi(v) : kDefaultVariant[P];
-      if (!march_variant(P, op->march_variant, &op->bx, &op->by)) {
-        set_error("wf_op_create_box: WF_MARCH_VARIANT out of range");
+      op->march_variant = tun.variant > 0 ? tun.variant - 1 : kDefaultVariant[P];
+      if (P >= 5) {
+        op->march_variant = 0;
+        march_ks_shape(P, &op->bx, &op->by);
+      } else if (!march_variant(P, op->march_variant, &op->bx, &op->by)) {
+        set_error("wf_op_create_box: wf_tuning.variant out of range");
         return WF_ERR_INVALID;
       }
       op->bz = 1;
@@ -815,13 +829,14 @@ int wf_op_create_box(int kind, int degree, int nx, int ny, int nz, const double*
         const int lz = (nz + nseg - 1) / nseg;
         if (lz < 3 && nseg > 1) break;
         const long items = (long)ncols * ((nz + lz - 1) / lz);
-        const double cost = (double)((items + 511) / 512) * (lz + 1.5);
+        const long resident = P >= 5 ? 256 : 512;   // workgroups per round: one 512-thread / two 256-thread per CU
+        const double cost = (double)((items + resident - 1) / resident) * (lz + 1.5);
         if (cost < best - 1e-9) {
           best = cost;
           op->lz = lz;
         }
       }
-      if (const char* l = std::getenv("WF_MARCH_LZ")) op->lz = std::max(1, std::atoi(l));
+      if (tun.lz > 0) op->lz = tun.lz;
     }
   }
   int rc;
@@ -890,15 +905,24 @@ int wf_op_create_dense_simplex(const wf_dense_desc* desc, wf_op** out)
   return WF_OK;
 }
 
+// the box marching kernels (one thread per column at P <= 4, two at P >= 5)
+static int launch_box_march(const wf_op* op, int lz0, const double* d_x, double* d_y, const int32_t* d_items, int nitems,
+                            hipStream_t s)
+{
+  if (op->P >= 5)
+    return launch_stiffness_march_ks_box(op->P, op->nx, op->ny, op->nz, op->lz, lz0, op->d_G6blk, op->d_D, op->dm, op->coeff,
+                                         d_x, d_y, d_items, nitems, s);
+  return launch_stiffness_march(op->P, op->march_variant, op->nx, op->ny, op->nz, op->lz, lz0, op->d_G6blk, op->d_D, op->dm,
+                                op->coeff, d_x, d_y, d_items, nitems, s);
+}
+
 int wf_op_apply(wf_op* op, const double* d_x, double* d_y, void* stream)
 {
   WF_REQUIRE(op && d_x && d_y, "wf_op_apply: null argument");
   hipStream_t s = (hipStream_t)stream;
   if (op->dense) return launch_stiffness_dense(op->dense, op->coeff, op->dense_clamp, d_x, d_y, s);
   if (op->structured) {
-    if (op->kind == WF_OP_STIFFNESS && op->march)
-      return launch_stiffness_march(op->P, op->march_variant, op->nx, op->ny, op->nz, op->lz, op->lz, op->d_G6blk, op->d_D,
-                                    op->dm, op->coeff, d_x, d_y, nullptr, 0, s);
+    if (op->kind == WF_OP_STIFFNESS && op->march) return launch_box_march(op, op->lz, d_x, d_y, nullptr, 0, s);
     if (op->kind == WF_OP_STIFFNESS)
       return launch_stiffness_box(op->P, op->nx, op->ny, op->nz, op->bx, op->by, op->bz, op->d_G6blk, op->d_D, op->dm,
                                   op->coeff, d_x, d_y, s);
@@ -907,7 +931,7 @@ int wf_op_apply(wf_op* op, const double* d_x, double* d_y, void* stream)
   switch (op->kind) {
     case WF_OP_STIFFNESS:
       if (op->have_plan == 1)
-        return launch_stiffness_march_idx(op->P, 0, op->plan, op->d_G6blk, op->d_D, op->dm, op->coeff, d_x, d_y, s);
+        return launch_stiffness_march_idx(op->P, op->plan, op->d_G6blk, op->d_D, op->dm, op->coeff, d_x, d_y, nullptr, 0, s);
       if (op->generic_unique)
         return launch_stiffness_generic_u(op->P, op->ncells, op->d_uoff, op->d_uniq, op->d_loc, op->d_G6blk, op->d_D,
                                           op->dm, op->coeff, d_x, d_y, s);
@@ -932,36 +956,16 @@ int wf_op_apply(wf_op* op, const double* d_x, double* d_y, void* stream)
   return WF_ERR_INVALID;
 }
 
-int wf_op_set_ghost_faces(wf_op* op, int ghost_x0, int ghost_y0, int ghost_z0)
+// uploads the interior / interface work-item lists (and the two interior halves)
+static int set_item_lists(wf_op* op, std::vector<int32_t> (&items)[4])
 {
-  WF_REQUIRE(op != nullptr, "wf_op_set_ghost_faces: null handle");
-  if (!(op->structured && op->kind == WF_OP_STIFFNESS && op->march)) {
-    set_error("wf_op_set_ghost_faces: only the marching box stiffness operator splits into interior/interface parts");
-    return WF_ERR_UNSUPPORTED;
-  }
-  const int nbx = (op->nx + op->bx - 1) / op->bx, nby = (op->ny + op->by - 1) / op->by;
-  // With a ghost plane below, the first z segment is kept short (WF_MARCH_LZ0, default 3 layers):
-  // only its first layer reads the ghost plane, but the whole segment has to wait for the halo, and
-  // the less interface work there is the earlier the reverse exchange can start under the interior.
-  op->lz0_split = op->lz;
-  if (ghost_z0) {
-    int lz0 = 3;
-    if (const char* e = std::getenv("WF_MARCH_LZ0")) lz0 = std::atoi(e);
-    op->lz0_split = std::max(1, std::min(lz0, op->lz));
-  }
-  const int ncols = nbx * nby, nseg = 1 + (std::max(op->nz - op->lz0_split, 0) + op->lz - 1) / op->lz;
-  std::vector<int32_t> items[4];
-  for (int seg = 0; seg < nseg; ++seg)
-    for (int col = 0; col < ncols; ++col) {
-      const int Bx = col % nbx, By = col / nbx;
-      // a work item is "interface" when it reads a ghost plane of x / adds into a ghost plane of y
-      const bool iface = (ghost_x0 && Bx == 0) || (ghost_y0 && By == 0) || (ghost_z0 && seg == 0);
-      items[iface ? 1 : 0].push_back(col + ncols * seg);
-    }
   // the interior halves let a caller hide BOTH halo directions: forward update under
   // half A, reverse update under half B (alternate items so both halves span the mesh)
+  items[2].clear();
+  items[3].clear();
   for (size_t q = 0; q < items[0].size(); ++q) items[2 + (q & 1)].push_back(items[0][q]);
   for (int k = 0; k < 4; ++k) {
+    if (op->d_items[k]) op->device_bytes -= (size_t)op->nitems[k] * sizeof(int32_t);
     (void)hipFree(op->d_items[k]);
     op->d_items[k] = nullptr;
     op->nitems[k] = (int)items[k].size();
@@ -974,19 +978,115 @@ int wf_op_set_ghost_faces(wf_op* op, int ghost_x0, int ghost_y0, int ghost_z0)
   return WF_OK;
 }
 
+int wf_op_set_ghost_faces(wf_op* op, int ghost_x0, int ghost_y0, int ghost_z0)
+{
+  WF_REQUIRE(op != nullptr, "wf_op_set_ghost_faces: null handle");
+  if (!(op->structured && op->kind == WF_OP_STIFFNESS && op->march)) {
+    set_error("wf_op_set_ghost_faces: only the marching box stiffness operator has lattice faces (wf_op_set_ghost_dofs "
+              "splits any marching operator)");
+    return WF_ERR_UNSUPPORTED;
+  }
+  const int nbx = (op->nx + op->bx - 1) / op->bx, nby = (op->ny + op->by - 1) / op->by;
+  // With a ghost plane below, the first z segment is kept short (wf_tuning.lz0, default 3 layers):
+  // only its first layer reads the ghost plane, but the whole segment has to wait for the halo, and
+  // the less interface work there is the earlier the reverse exchange can start under the interior.
+  op->lz0_split = op->lz;
+  if (ghost_z0) op->lz0_split = std::max(1, std::min(op->tun.lz0 > 0 ? op->tun.lz0 : 3, op->lz));
+  const int ncols = nbx * nby, nseg = 1 + (std::max(op->nz - op->lz0_split, 0) + op->lz - 1) / op->lz;
+  std::vector<int32_t> items[4];
+  for (int seg = 0; seg < nseg; ++seg)
+    for (int col = 0; col < ncols; ++col) {
+      const int Bx = col % nbx, By = col / nbx;
+      // a work item is "interface" when it reads a ghost plane of x / adds into a ghost plane of y
+      const bool iface = (ghost_x0 && Bx == 0) || (ghost_y0 && By == 0) || (ghost_z0 && seg == 0);
+      items[iface ? 1 : 0].push_back(col + ncols * seg);
+    }
+  return set_item_lists(op, items);
+}
+
+int wf_op_set_ghost_dofs(wf_op* op, const int32_t* h_ghost_positions, int32_t nghosts)
+{
+  WF_REQUIRE(op != nullptr && nghosts >= 0 && (nghosts == 0 || h_ghost_positions), "wf_op_set_ghost_dofs: bad argument");
+  const bool box = op->structured && op->kind == WF_OP_STIFFNESS && op->march;
+  const bool idx = !op->structured && op->kind == WF_OP_STIFFNESS && op->have_plan == 1;
+  if (!box && !idx) {
+    set_error("wf_op_set_ghost_dofs: only the marching stiffness operators split into interior / interface work items "
+              "(this operator runs a batch kernel)");
+    return WF_ERR_UNSUPPORTED;
+  }
+  std::vector<char> ghost((size_t)op->ndofs, 0);
+  for (int32_t g = 0; g < nghosts; ++g) {
+    WF_REQUIRE(h_ghost_positions[g] >= 0 && h_ghost_positions[g] < op->ndofs, "wf_op_set_ghost_dofs: ghost position out of range");
+    ghost[h_ghost_positions[g]] = 1;
+  }
+  const int P = op->P;
+  std::vector<int32_t> items[4];
+  if (box) {
+    const int NX = P * op->nx + 1, NY = P * op->ny + 1;
+    const size_t plane = (size_t)NX * NY;
+    // a z ghost plane below shortens the first segment (see wf_op_set_ghost_faces)
+    bool gz = false;
+    for (size_t g = 0; g < plane && !gz; ++g) gz = ghost[g] != 0;
+    op->lz0_split = op->lz;
+    if (gz) op->lz0_split = std::max(1, std::min(op->tun.lz0 > 0 ? op->tun.lz0 : 3, op->lz));
+    const int nbx = (op->nx + op->bx - 1) / op->bx, nby = (op->ny + op->by - 1) / op->by;
+    const int ncols = nbx * nby, nseg = 1 + (std::max(op->nz - op->lz0_split, 0) + op->lz - 1) / op->lz;
+    for (int seg = 0; seg < nseg; ++seg) {
+      const int z0 = seg == 0 ? 0 : op->lz0_split + (seg - 1) * op->lz;
+      const int z1 = std::min(op->nz, seg == 0 ? op->lz0_split : z0 + op->lz);
+      for (int col = 0; col < ncols; ++col) {
+        const int Bx = col % nbx, By = col / nbx;
+        const int I0 = P * Bx * op->bx, J0 = P * By * op->by;
+        const int I1 = std::min(NX - 1, I0 + P * op->bx), J1 = std::min(NY - 1, J0 + P * op->by);
+        bool iface = false;
+        for (int K = P * z0; K <= P * z1 && !iface; ++K)
+          for (int J = J0; J <= J1 && !iface; ++J) {
+            const char* row = &ghost[(size_t)I0 + (size_t)NX * J + plane * K];
+            for (int I = 0; I <= I1 - I0; ++I)
+              if (row[I]) {
+                iface = true;
+                break;
+              }
+          }
+        items[iface ? 1 : 0].push_back(col + ncols * seg);
+      }
+    }
+  } else {
+    // an item is interface iff its dof tile (base + pattern offsets) contains a ghost position
+    const int nit = op->plan.nitems;
+    const size_t tsize = (size_t)op->plan.tile_size;
+    std::vector<int32_t> base(nit), pat(nit), pat_off((size_t)op->plan_patterns * tsize);
+    WF_HIP_CHECK(hipMemcpy(base.data(), op->plan.d_item_base, (size_t)nit * sizeof(int32_t), hipMemcpyDeviceToHost));
+    WF_HIP_CHECK(hipMemcpy(pat.data(), op->plan.d_item_pattern, (size_t)nit * sizeof(int32_t), hipMemcpyDeviceToHost));
+    WF_HIP_CHECK(hipMemcpy(pat_off.data(), op->plan.d_pat_off, pat_off.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    for (int it = 0; it < nit; ++it) {
+      const int32_t* off = &pat_off[(size_t)pat[it] * tsize];
+      bool iface = false;
+      for (size_t e = 0; e < tsize; ++e)
+        if (off[e] >= 0 && ghost[(size_t)base[it] + off[e]]) {
+          iface = true;
+          break;
+        }
+      items[iface ? 1 : 0].push_back(it);
+    }
+  }
+  return set_item_lists(op, items);
+}
+
 int wf_op_apply_part(wf_op* op, const double* d_x, double* d_y, int part, void* stream)
 {
   WF_REQUIRE(op && d_x && d_y, "wf_op_apply_part: null argument");
   if (part == WF_PART_ALL) return wf_op_apply(op, d_x, d_y, stream);
   WF_REQUIRE(part >= WF_PART_INTERIOR && part <= WF_PART_INTERIOR_B, "wf_op_apply_part: unknown part");
   if (!op->have_parts) {
-    set_error("wf_op_apply_part: call wf_op_set_ghost_faces first");
+    set_error("wf_op_apply_part: call wf_op_set_ghost_dofs / wf_op_set_ghost_faces first");
     return WF_ERR_INVALID;
   }
   const int k = part - 1;   // WF_PART_INTERIOR, _INTERFACE, _INTERIOR_A, _INTERIOR_B
   if (op->nitems[k] == 0) return WF_OK;
-  return launch_stiffness_march(op->P, op->march_variant, op->nx, op->ny, op->nz, op->lz, op->lz0_split, op->d_G6blk, op->d_D,
-                                op->dm, op->coeff, d_x, d_y, op->d_items[k], op->nitems[k], (hipStream_t)stream);
+  if (op->structured) return launch_box_march(op, op->lz0_split, d_x, d_y, op->d_items[k], op->nitems[k], (hipStream_t)stream);
+  return launch_stiffness_march_idx(op->P, op->plan, op->d_G6blk, op->d_D, op->dm, op->coeff, d_x, d_y, op->d_items[k],
+                                    op->nitems[k], (hipStream_t)stream);
 }
 
 int wf_op_info(const wf_op* op, wf_op_info_t* info)
@@ -1012,6 +1112,12 @@ int wf_op_info(const wf_op* op, wf_op_info_t* info)
   info->device_bytes = op->device_bytes;
   info->items_interior = op->nitems[0];
   info->items_interface = op->nitems[1];
+  info->kernel = op->dense ? WF_KERNEL_DENSE_SIMPLEX : op->kernel_id;
+  info->plan_items = op->have_plan ? op->plan.nitems : 0;
+  info->plan_patterns = op->have_plan ? op->plan_patterns : 0;
+  info->plan_lz = op->have_plan ? op->plan.lz : (op->structured && op->march ? op->lz : 0);
+  info->plan_reoriented = op->plan_reoriented;
+  info->plan_fill = op->plan_fill;
   return WF_OK;
 }
 

@@ -183,7 +183,11 @@ extern "C" int wf_cg(const wf_cg_desc* d, double* d_x, const double* d_b, int* i
   if ((rc = read(kS_rr, &rr0)) != WF_OK) return rc;
   rr = rr0;
   const double rtol2 = d->rtol * d->rtol;
+#ifdef WF_DIAG
   const bool verbose = std::getenv("WF_CG_VERBOSE") != nullptr;
+#else
+  constexpr bool verbose = false;
+#endif
   if (verbose) std::fprintf(stderr, "wf_cg: n = %lld rnorm0 = %.17g\n", (long long)n, rr0);
   int k = 0;
   if (rr0 > 0.0) {

@@ -123,12 +123,12 @@ struct wf_updater {
   int flags = 0;
   hipStream_t comm_stream = nullptr;         // the exchange runs here unless WF_UPDATER_INLINE
   hipEvent_t ev_packed = nullptr, ev_done = nullptr;
-  // streams of wf_op_apply_overlapped: the halo chain runs on a high-priority side stream,
-  // the interior cells on a stream whose CU mask leaves a few CUs free, so that the small
-  // pack / RCCL / unpack kernels never queue behind the interior's resident workgroups
+  // streams of wf_op_apply_overlapped: a low-priority stream for the interior while the halo chain runs on
+  // the caller's stream (default), or a high-priority side stream for the chain (WF_UPDATER_CHAIN_ON_SIDE).
+  // (A CU-masked interior stream that keeps a few CUs free for the small pack / RCCL / unpack kernels was
+  // measured and dropped: 0.476 vs 0.346 ms per step, every event wait to or from the masked queue 40-60 us.)
   hipStream_t side_stream = nullptr;
-  hipStream_t interior_stream = nullptr;      // nullptr: interior runs on the caller's stream
-  hipStream_t low_stream = nullptr;           // low-priority stream for the interior when the halo chain runs on the caller's
+  hipStream_t low_stream = nullptr;
   hipEvent_t ev_main = nullptr, ev_side = nullptr, ev_interior = nullptr;
 };
 
@@ -146,7 +146,6 @@ void free_updater(wf_updater* u)
   if (u->ev_main) (void)hipEventDestroy(u->ev_main);
   if (u->ev_side) (void)hipEventDestroy(u->ev_side);
   if (u->ev_interior) (void)hipEventDestroy(u->ev_interior);
-  if (u->interior_stream) (void)hipStreamDestroy(u->interior_stream);
   if (u->low_stream) (void)hipStreamDestroy(u->low_stream);
   if (u->comm_stream) (void)hipStreamDestroy(u->comm_stream);
   if (u->side_stream) (void)hipStreamDestroy(u->side_stream);
@@ -260,12 +259,10 @@ int wf_comm_create(const char* id, int rank, int nranks, wf_comm** out)
 
 // Rendezvous through a file for launchers without MPI: rank 0 writes the id to
 // `path` (atomically, via rename), the others poll for it.  `path` must be unique
-// per job (e.g. contain MASTER_PORT); rank 0 removes it once the communicator is up.
-int wf_comm_create_from_file(const char* path, int rank, int nranks, double timeout_s, wf_comm** out)
+// per job (e.g. contain MASTER_PORT).
+int wf_comm_rendezvous_file(const char* path, int rank, double timeout_s, char* id)
 {
-  WF_REQUIRE(path && out, "wf_comm_create_from_file: null argument");
-  *out = nullptr;
-  char id[WF_COMM_ID_BYTES];
+  WF_REQUIRE(path && id && rank >= 0, "wf_comm_rendezvous_file: bad argument");
   if (rank == 0) {
     int rc = wf_comm_unique_id(id);
     if (rc != WF_OK) return rc;
@@ -273,32 +270,42 @@ int wf_comm_create_from_file(const char* path, int rank, int nranks, double time
     FILE* f = std::fopen(tmp.c_str(), "wb");
     if (!f || std::fwrite(id, 1, WF_COMM_ID_BYTES, f) != WF_COMM_ID_BYTES) {
       if (f) std::fclose(f);
-      wf::set_error(std::string("wf_comm_create_from_file: cannot write ") + tmp);
+      wf::set_error(std::string("wf_comm_rendezvous_file: cannot write ") + tmp);
       return WF_ERR_COMM;
     }
     std::fclose(f);
     if (std::rename(tmp.c_str(), path) != 0) {
-      wf::set_error(std::string("wf_comm_create_from_file: cannot publish ") + path);
+      wf::set_error(std::string("wf_comm_rendezvous_file: cannot publish ") + path);
       return WF_ERR_COMM;
     }
-  } else {
-    const auto t0 = std::chrono::steady_clock::now();
-    for (;;) {
-      struct stat st;
-      if (stat(path, &st) == 0 && st.st_size == WF_COMM_ID_BYTES) {
-        FILE* f = std::fopen(path, "rb");
-        const bool ok = f && std::fread(id, 1, WF_COMM_ID_BYTES, f) == WF_COMM_ID_BYTES;
-        if (f) std::fclose(f);
-        if (ok) break;
-      }
-      if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) {
-        wf::set_error(std::string("wf_comm_create_from_file: timed out waiting for ") + path);
-        return WF_ERR_COMM;
-      }
-      std::this_thread::sleep_for(std::chrono::milliseconds(20));
-    }
+    return WF_OK;
   }
-  int rc = wf_comm_create(id, rank, nranks, out);
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    struct stat st;
+    if (stat(path, &st) == 0 && st.st_size == WF_COMM_ID_BYTES) {
+      FILE* f = std::fopen(path, "rb");
+      const bool ok = f && std::fread(id, 1, WF_COMM_ID_BYTES, f) == WF_COMM_ID_BYTES;
+      if (f) std::fclose(f);
+      if (ok) return WF_OK;
+    }
+    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) {
+      wf::set_error(std::string("wf_comm_rendezvous_file: timed out waiting for ") + path);
+      return WF_ERR_COMM;
+    }
+    std::this_thread::sleep_for(std::chrono::milliseconds(20));
+  }
+}
+
+// rendezvous + ncclCommInitRank; rank 0 removes the file once the communicator is up
+int wf_comm_create_from_file(const char* path, int rank, int nranks, double timeout_s, wf_comm** out)
+{
+  WF_REQUIRE(path && out, "wf_comm_create_from_file: null argument");
+  *out = nullptr;
+  char id[WF_COMM_ID_BYTES];
+  int rc = wf_comm_rendezvous_file(path, rank, timeout_s, id);
+  if (rc != WF_OK) return rc;
+  rc = wf_comm_create(id, rank, nranks, out);
   if (rank == 0) (void)unlink(path);   // every rank has read it: CommInitRank returns only when all joined
   return rc;
 }
@@ -399,27 +406,6 @@ int wf_updater_create(wf_comm* comm, const wf_updater_desc* desc, wf_updater** o
   WF_HIP_CHECK(hipStreamCreateWithPriority(&u->comm_stream, hipStreamNonBlocking, prio_high));
   WF_HIP_CHECK(hipStreamCreateWithPriority(&u->side_stream, hipStreamNonBlocking, prio_high));
   WF_HIP_CHECK(hipStreamCreateWithPriority(&u->low_stream, hipStreamNonBlocking, prio_low));
-  // Optional: CUs kept free of interior workgroups through a CU-masked stream
-  // (WF_OVERLAP_RESERVE_CUS = n).  Measured on MI355X (bench.py --periodic x, ms per step):
-  // n = 0: 0.346, n = 4 or 8: 0.476 -- the halo chain then starts at once (RCCL kernel 12 us instead
-  // of 115 us queued behind the interior's resident workgroups) but every event wait between the
-  // masked queue and the other streams costs 40-60 us.  Off by default.
-  {
-    int reserve = 0;
-    if (const char* e = std::getenv("WF_OVERLAP_RESERVE_CUS")) reserve = std::atoi(e);
-    int dev = 0, ncu = 0;
-    WF_HIP_CHECK(hipGetDevice(&dev));
-    WF_HIP_CHECK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
-    if (reserve > 0 && reserve < ncu && !u->send_nb.empty() + !u->recv_nb.empty() > 0) {
-      std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
-      for (int c = 0; c < ncu - reserve; ++c) mask[c / 32] |= 1u << (c % 32);
-      hipStream_t s = nullptr;
-      if (hipExtStreamCreateWithCUMask(&s, (uint32_t)mask.size(), mask.data()) == hipSuccess)
-        u->interior_stream = s;
-      else
-        (void)hipGetLastError();   // not supported here: the interior runs on the caller's stream
-    }
-  }
   WF_HIP_CHECK(hipEventCreateWithFlags(&u->ev_interior, hipEventDisableTiming));
   WF_HIP_CHECK(hipEventCreateWithFlags(&u->ev_packed, hipEventDisableTiming));
   WF_HIP_CHECK(hipEventCreateWithFlags(&u->ev_done, hipEventDisableTiming));
@@ -500,10 +486,10 @@ int wf_op_apply_overlapped(wf_op* op, wf_updater* u, double* d_x, double* d_y, v
   // is the longer of the two, so the caller's stream continues behind the reverse unpack with no
   // cross-stream wait on the critical path (the interior finished earlier; waiting on a signalled
   // event is free), where the mirror arrangement paid ~17 us of event latency before the next
-  // kernel (rocprofv3 kernel trace of bench.py --periodic xyz).  WF_OVERLAP_CHAIN_ON_SIDE=1 selects
+  // kernel (rocprofv3 kernel trace of bench.py --periodic xyz).  WF_UPDATER_CHAIN_ON_SIDE selects
   // the mirror arrangement (chain on the updater's high-priority stream, interior on the caller's).
-  static const bool chain_on_side = std::getenv("WF_OVERLAP_CHAIN_ON_SIDE") != nullptr;
-  if (!chain_on_side && !u->interior_stream) {
+  const bool chain_on_side = (u->flags & WF_UPDATER_CHAIN_ON_SIDE) != 0;
+  if (!chain_on_side) {
     WF_HIP_CHECK(hipEventRecord(u->ev_main, main));
     WF_HIP_CHECK(hipStreamWaitEvent(u->low_stream, u->ev_main, 0));
     if ((rc = wf_op_apply_part(op, d_x, d_y, WF_PART_INTERIOR, u->low_stream)) != WF_OK) return rc;
@@ -520,13 +506,7 @@ int wf_op_apply_overlapped(wf_op* op, wf_updater* u, double* d_x, double* d_y, v
   if ((rc = fwd_begin(u, d_x, side, true)) != WF_OK || (rc = fwd_end(u, d_x, side, true)) != WF_OK) return rc;
   if ((rc = wf_op_apply_part(op, d_x, d_y, WF_PART_INTERFACE, side)) != WF_OK) return rc;
   if ((rc = rev_begin(u, d_y, side, true)) != WF_OK || (rc = rev_end(u, d_y, side, true)) != WF_OK) return rc;
-  if (u->interior_stream) {
-    WF_HIP_CHECK(hipStreamWaitEvent(u->interior_stream, u->ev_main, 0));
-    if ((rc = wf_op_apply_part(op, d_x, d_y, WF_PART_INTERIOR, u->interior_stream)) != WF_OK) return rc;
-    WF_HIP_CHECK(hipEventRecord(u->ev_interior, u->interior_stream));
-    WF_HIP_CHECK(hipStreamWaitEvent(main, u->ev_interior, 0));
-  } else if ((rc = wf_op_apply_part(op, d_x, d_y, WF_PART_INTERIOR, main)) != WF_OK)
-    return rc;
+  if ((rc = wf_op_apply_part(op, d_x, d_y, WF_PART_INTERIOR, main)) != WF_OK) return rc;
   WF_HIP_CHECK(hipEventRecord(u->ev_side, side));
   WF_HIP_CHECK(hipStreamWaitEvent(main, u->ev_side, 0));
   return WF_OK;

@@ -61,13 +61,16 @@ inline int cells_per_batch(int P) { return 256 / ((P + 1) * (P + 1)); }
 int launch_geometry_hex(int P, int ncells, const double* d_xverts, const int32_t* d_geom_dofmap,
                         const double* d_pts, const double* d_wts, int use_fabs, int clamp,
                         double* d_G9, double* d_G6blk, double* d_detJ, hipStream_t s);
+// lattice plans with a fill (cells per cell slot) below this keep the batch kernel: the marching kernels
+// read geometry for every slot of a column, empty or not
+constexpr double kMinPlanFill = 0.55;
 int launch_geometry_box(int P, int nx, int ny, int nz, int bx, int by, int bz, const double* d_xverts,
                         const double* d_pts, const double* d_wts, int use_fabs, int clamp,
                         double* d_G6blk, double* d_detJ_lattice, hipStream_t s);
-int launch_geometry_hex_slots(int P, int ncells, const double* d_xverts, const int32_t* d_geom_dofmap,
-                              const int32_t* d_slot_of, const double* d_pts, const double* d_wts, int use_fabs,
-                              int clamp, double* d_G6blk, hipStream_t s);
-int launch_pack_G6(int P, int ncells, const double* d_G9, double* d_G6blk, hipStream_t s);
+int launch_geometry_hex_slots(int P, int CB, int ncells, const double* d_xverts, const int32_t* d_geom_dofmap,
+                              const int32_t* d_slot_of, const uint8_t* d_orient, const double* d_pts, const double* d_wts,
+                              int use_fabs, int clamp, double* d_G6blk, hipStream_t s);
+int launch_pack_G6(int P, int CB, int ncells, const double* d_G9, double* d_G6blk, hipStream_t s);
 int launch_stiffness_generic(int P, int ncells, const int32_t* d_dofmap, const double* d_G6blk,
                              const double* d_D, const DMat& dm, double coeff, const double* d_x,
                              double* d_y, hipStream_t s);
@@ -81,11 +84,14 @@ bool march_variant(int P, int variant, int* bx, int* by);
 int launch_stiffness_march(int P, int variant, int nx, int ny, int nz, int lz, int lz0, const double* d_G6blk,
                            const double* d_D, const DMat& dm, double coeff, const double* d_x, double* d_y,
                            const int32_t* d_items, int nitems, hipStream_t s);
-// indexed marching kernel for arbitrary dofmaps (generic_plan.cpp, stiffness_march_idx.hip)
+// indexed marching kernels for arbitrary dofmaps (generic_plan.cpp, stiffness_march_idx.hip, stiffness_march_ks.hip)
 struct MarchPlan {
   bool ok = false;                      // false: the mesh does not tile into lattice columns
   int BX = 0, BY = 0, lz = 0, nitems = 0, npatterns = 0, tile_size = 0;
+  int reoriented = 0, ncomponents = 0;  // cells looked at in a rotated / reflected frame; lattice components
+  double fill = 0.0;                    // cells / cell slots
   std::vector<int32_t> slot_cell;       // [nitems * lz * BX * BY] cell index or -1, slot order [layer][ly][lx]
+  std::vector<uint8_t> cell_orient;     // [ncells] orientation code (orient_decode)
   std::vector<int32_t> item_base;       // [nitems] smallest dof of the item
   std::vector<int32_t> item_pattern;    // [nitems]
   std::vector<int32_t> item_layers;     // [nitems] non-empty layers (<= lz)
@@ -95,12 +101,31 @@ struct MarchPlanDev {
   int nitems = 0, lz = 0, tile_size = 0, variant = 0;
   int32_t *d_item_base = nullptr, *d_item_pattern = nullptr, *d_item_layers = nullptr, *d_pat_off = nullptr;
 };
-int build_march_plan(int P, size_t ncells, const int32_t* tdm, int BX, int BY, int lz_max, int lz_fixed, MarchPlan* plan);
-size_t march_idx_lds_bytes(int P, int BX, int BY, int lz);
+// cell orientations: lattice axis m of a cell runs along its own axis raw_axis[m], reversed when flip[m]
+void orient_decode(int code, int raw_axis[3], int flip[3]);
+int orient_local_index(int code, int n, int i, int j, int k);   // raw tensor index of lattice-frame node (i, j, k)
+int orient_sign(int code);                                       // +1 rotation, -1 reflection
+int build_march_plan(int P, size_t ncells, const int32_t* tdm, int BX, int BY, int lz_max, int lz_fixed, bool normalise,
+                     MarchPlan* plan);
+constexpr int OP_KIND_STIFFNESS = 0, OP_KIND_MASS = 1;
+// column cross-section, LDS need and LDS budget (per workgroup) of the indexed marching kernel of (kind, P)
+void march_idx_shape(int kind, int P, int* bx, int* by);
+size_t march_idx_lds_bytes(int kind, int P, int BX, int BY, int lz);
+size_t march_idx_lds_budget(int kind, int P);
 int launch_mass_march_idx(int P, const MarchPlanDev& pd, const double* d_detJblk, const double* d_phi1, const DMat& pm,
                           const double* d_x, double* d_y, hipStream_t s);
-int launch_stiffness_march_idx(int P, int variant, const MarchPlanDev& pd, const double* d_G6blk, const double* d_D,
-                               const DMat& dm, double coeff, const double* d_x, double* d_y, hipStream_t s);
+int launch_stiffness_march_idx(int P, const MarchPlanDev& pd, const double* d_G6blk, const double* d_D,
+                               const DMat& dm, double coeff, const double* d_x, double* d_y, const int32_t* d_items,
+                               int nitems, hipStream_t s);
+// k-split marching kernel, P = 5..7 (stiffness_march_ks.hip)
+bool march_ks_shape(int P, int* bx, int* by);
+size_t march_ks_lds_bytes(int P, int BX, int BY, int lz, bool idx);
+int launch_stiffness_march_ks_box(int P, int nx, int ny, int nz, int lz, int lz0, const double* d_G6blk, const double* d_D,
+                                  const DMat& dm, double coeff, const double* d_x, double* d_y, const int32_t* d_items,
+                                  int nitems, hipStream_t s);
+int launch_stiffness_march_ks_idx(int P, const MarchPlanDev& pd, const double* d_G6blk, const double* d_D, const DMat& dm,
+                                  double coeff, const double* d_x, double* d_y, const int32_t* d_items, int nitems,
+                                  hipStream_t s);
 // dense simplex operator (stiffness_dense.hip)
 struct DenseOpData;
 int dense_setup(int nd, int nq, int ncells, int ndofs, const int32_t* dofmap, const double* dphi,

@@ -1,25 +1,30 @@
-// Host-side work plan of the indexed marching stiffness kernel k_stiffness_march_idx
-// (stiffness_march_idx.hip): the production kernel for an ARBITRARY dofmap.
-// StiffnessOperator(V, ...) of common/operators.hpp:137-201 visits its cells in dofmap
-// order; cells are summed independently (operators.hpp:188-199), so the operator may
-// regroup them freely.
+// Host-side work plan of the indexed marching kernels k_march_idx / k_march_idx_ks
+// (stiffness_march_idx.hip, stiffness_march_ks.hip): the production kernels for an ARBITRARY
+// dofmap.  StiffnessOperator(V, ...) of common/operators.hpp:137-201 visits its cells in dofmap
+// order; cells are summed independently (operators.hpp:188-199), so the operator may regroup
+// them freely -- and may look at every cell in whichever of the 48 orientations of the reference
+// cube suits it, as long as dofs and geometry are relabelled together.
 //
 // The marching box kernel (stiffness_march.hip) owes its speed to columns of BX x BY x lz
 // cells: the dof planes between the layers never leave the workgroup.  Nothing in that
 // needs the lexicographic numbering -- only the ADDRESSES of the column's dofs do.  The
-// plan therefore finds such columns in any conforming hexahedral mesh whose cells link up
-// like a lattice, whatever its cell order and dof numbering (e.g. a DOLFINx box mesh):
-//   1. lattice detection: cells are linked through faces whose four corner dofs and
-//      orientation agree; a breadth-first walk over the links gives every cell integer
-//      coordinates (cx, cy, cz);
-//   2. columns of BX x BY cells are cut into segments of <= lz layers = work items;
-//   3. per item, the dof of every position of the column's dof tile
+// plan therefore finds such columns in any conforming hexahedral mesh, whatever its cell order,
+// dof numbering and local cell orientations (a DOLFINx box mesh, a gmsh multi-block mesh):
+//   1. face links: two cells are linked when they share the four corner dofs of a face;
+//   2. lattice placement: a breadth-first walk over the links gives every cell integer
+//      coordinates (cx, cy, cz) and an ORIENTATION (signed permutation of its local axes) under
+//      which its axes agree with the lattice.  A cell is only placed where every already placed
+//      cell among its 26 lattice neighbours shares exactly the corner dofs the lattice says it
+//      should (so irregular vertices -- three or five cells around an edge, O-grids -- and
+//      periodic wrap-arounds cut the lattice into COMPONENTS instead of breaking the plan);
+//   3. columns of BX x BY cells are cut into segments of <= lz layers = work items;
+//   4. per item, the dof of every position of the column's dof tile
 //      [P lz + 1][P BY + 1][P BX + 1] is recorded (as an offset from the item's smallest
 //      dof, -1 where no cell covers the position) and checked for conformity: all cells
 //      covering a position must name the same dof.  Identical tables are stored once
 //      (PATTERNS), so a regularly numbered mesh keeps its index data in L2.
-// Meshes that do not link up (or do not tile consistently) are reported as such; the
-// caller falls back to the batch kernel k_stiffness_generic_u.
+// The plan reports its fill (cells per cell slot); the caller falls back to the batch kernel
+// k_stiffness_generic_u when the columns are mostly empty.
 #include <algorithm>
 #include <array>
 #include <cstring>
@@ -30,13 +35,46 @@
 
 namespace wf {
 
+// ---- cell orientations ---------------------------------------------------------------
+// code = 8 * perm + flips.  Lattice axis m of the cell runs along the cell's own ("raw") axis
+// kAxisPerm[perm][m], reversed when bit m of `flips` is set.
+static const int kAxisPerm[6][3] = {{0, 1, 2}, {0, 2, 1}, {1, 0, 2}, {1, 2, 0}, {2, 0, 1}, {2, 1, 0}};
+
+void orient_decode(int code, int raw_axis[3], int flip[3])
+{
+  for (int m = 0; m < 3; ++m) {
+    raw_axis[m] = kAxisPerm[code >> 3][m];
+    flip[m] = (code >> m) & 1;
+  }
+}
+
+// raw tensor index (x fastest) of the lattice-frame node (i, j, k), n nodes per direction
+int orient_local_index(int code, int n, int i, int j, int k)
+{
+  int ra[3], fl[3];
+  orient_decode(code, ra, fl);
+  const int l[3] = {i, j, k};
+  int r[3] = {0, 0, 0};
+  for (int m = 0; m < 3; ++m) r[ra[m]] = fl[m] ? n - 1 - l[m] : l[m];
+  return r[0] + n * (r[1] + n * r[2]);
+}
+
+// +1 for a rotation, -1 for a reflection of the reference cube
+int orient_sign(int code)
+{
+  static const int perm_sign[6] = {1, -1, -1, 1, 1, -1};
+  int s = perm_sign[code >> 3];
+  for (int m = 0; m < 3; ++m)
+    if ((code >> m) & 1) s = -s;
+  return s;
+}
+
 namespace {
 
 struct FaceRec {
   std::array<int32_t, 4> key;   // sorted corner dofs
-  std::array<int32_t, 4> ord;   // corner dofs in the cell's tensor order
   int32_t cell;
-  int8_t axis, side;
+  int8_t face;                  // 2 * raw axis + side
   bool operator<(const FaceRec& o) const { return key < o.key; }
 };
 
@@ -54,11 +92,19 @@ struct KeyHash {
   size_t operator()(const std::array<int32_t, 4>& k) const { return (size_t)fnv(k.data(), sizeof(k)); }
 };
 
+// corner q (bits = lattice-frame position) of a cell under orientation `code`: index 0..7 of the raw corner
+inline int oriented_corner(int code, int q)
+{
+  return orient_local_index(code, 2, q & 1, (q >> 1) & 1, (q >> 2) & 1);
+}
+
 }  // namespace
 
-// tdm: tensor-ordered dofmap [ncells][nd].  Returns WF_OK and plan->ok = true when the mesh
-// tiles into columns; plan->ok = false (still WF_OK) when it does not.
-int build_march_plan(int P, size_t ncells, const int32_t* tdm, int BX, int BY, int lz_max, int lz_fixed, MarchPlan* plan)
+// tdm: tensor-ordered dofmap [ncells][nd] (the caller's cell frames).  Returns WF_OK and plan->ok =
+// true when the mesh tiles into columns; plan->ok = false (still WF_OK) when it does not.
+// normalise = false requires the cells' local axes to agree as given (orientation code 0 everywhere).
+int build_march_plan(int P, size_t ncells, const int32_t* tdm, int BX, int BY, int lz_max, int lz_fixed, bool normalise,
+                     MarchPlan* plan)
 {
   int lz = lz_max;
   const int n = P + 1, n2 = n * n, nd = n * n2, CB = BX * BY;
@@ -68,47 +114,50 @@ int build_march_plan(int P, size_t ncells, const int32_t* tdm, int BX, int BY, i
   plan->BY = BY;
   plan->lz = lz_max;
   plan->nitems = 0;
+  plan->reoriented = 0;
+  plan->ncomponents = 0;
+  plan->fill = 0.0;
+  plan->cell_orient.assign(ncells, 0);
   if (ncells == 0) {
     plan->ok = true;
+    plan->fill = 1.0;
     return WF_OK;
   }
 
-  // ---- 1. face links -----------------------------------------------------------
+  // corner dofs of every cell in its own frame, corner q = a + 2b + 4c
+  std::vector<std::array<int32_t, 8>> corner(ncells);
+  for (size_t c = 0; c < ncells; ++c) {
+    const int32_t* d = tdm + c * nd;
+    for (int q = 0; q < 8; ++q)
+      corner[c][q] = d[((q & 1) ? P : 0) + n * (((q >> 1) & 1 ? P : 0) + n * ((q >> 2) & 1 ? P : 0))];
+  }
+
+  // ---- 1. face links: nb[c][raw face] = (cell, its raw face) ----------------------------
   std::vector<std::array<int32_t, 6>> nb(ncells);
   for (auto& a : nb) a.fill(-1);
   {
     std::vector<FaceRec> faces;
     faces.reserve(ncells * 6);
-    for (size_t c = 0; c < ncells; ++c) {
-      const int32_t* d = tdm + c * nd;
-      int32_t v[8];
-      for (int q = 0; q < 8; ++q) v[q] = d[((q & 1) ? P : 0) + n * (((q >> 1) & 1 ? P : 0) + n * ((q >> 2) & 1 ? P : 0))];
+    for (size_t c = 0; c < ncells; ++c)
       for (int axis = 0; axis < 3; ++axis)
         for (int side = 0; side < 2; ++side) {
           FaceRec f;
           int m = 0;
           for (int q = 0; q < 8; ++q)
-            if (((q >> axis) & 1) == side) f.ord[m++] = v[q];
-          f.key = f.ord;
+            if (((q >> axis) & 1) == side) f.key[m++] = corner[c][q];
           std::sort(f.key.begin(), f.key.end());
           f.cell = (int32_t)c;
-          f.axis = (int8_t)axis;
-          f.side = (int8_t)side;
+          f.face = (int8_t)(2 * axis + side);
           faces.push_back(f);
         }
-    }
     std::sort(faces.begin(), faces.end());
     for (size_t a = 0; a + 1 < faces.size(); ++a) {
       const FaceRec &f = faces[a], &g = faces[a + 1];
-      if (f.key != g.key) continue;
-      if (a + 2 < faces.size() && faces[a + 2].key == f.key) return WF_OK;   // non-manifold: not a lattice
-      // consistent orientation: same axis, opposite sides, same in-face corner order
-      if (f.axis == g.axis && f.side != g.side && f.ord == g.ord) {
-        nb[f.cell][2 * f.axis + f.side] = g.cell;
-        nb[g.cell][2 * g.axis + g.side] = f.cell;
-      } else if (f.cell != g.cell) {
-        return WF_OK;   // two cells meet with different orientations: no global lattice
-      }
+      if (f.key != g.key || f.cell == g.cell) continue;
+      if (a + 2 < faces.size() && faces[a + 2].key == f.key) return WF_OK;   // three cells on one face: not a manifold mesh
+      if (f.key[0] == f.key[1] || f.key[1] == f.key[2] || f.key[2] == f.key[3]) continue;   // degenerate face
+      nb[f.cell][f.face] = g.cell;
+      nb[g.cell][g.face] = f.cell;
     }
   }
   std::vector<int32_t> key(ncells), by_key(ncells);
@@ -118,10 +167,73 @@ int build_march_plan(int P, size_t ncells, const int32_t* tdm, int BX, int BY, i
   }
   std::stable_sort(by_key.begin(), by_key.end(), [&](int32_t a, int32_t b) { return key[a] < key[b]; });
 
-  // ---- 2. lattice coordinates (per connected component) -----------------------------
+  // ---- 2. lattice placement (components, coordinates, orientations) -------------------
   std::vector<std::array<int32_t, 3>> xyz(ncells);
   std::vector<int32_t> comp(ncells, -1);
+  std::vector<uint8_t>& orient = plan->cell_orient;
   std::vector<std::array<int32_t, 3>> cmin;
+  std::unordered_map<std::array<int32_t, 4>, int32_t, KeyHash> at;   // (component, x, y, z) -> cell
+  at.reserve(ncells * 2);
+
+  // orientation of cell `o` such that its lattice-frame face (axis a, side 1 - s) carries, corner by
+  // corner, the dofs `want[4]` (in-face positions (beta, gamma) over the other two lattice axes, beta fastest);
+  // -1 if there is none
+  auto orientation_from_face = [&](int32_t o, int a, int s, const int32_t want[4]) -> int {
+    int r[4];
+    for (int m = 0; m < 4; ++m) {
+      r[m] = -1;
+      for (int q = 0; q < 8; ++q)
+        if (corner[o][q] == want[m]) {
+          if (r[m] >= 0) return -1;   // a dof twice among the corners (periodic cell one cell wide)
+          r[m] = q;
+        }
+      if (r[m] < 0) return -1;
+    }
+    const int b = (a + 1) % 3 < (a + 2) % 3 ? (a + 1) % 3 : (a + 2) % 3, c = 3 - a - b;   // in-face lattice axes, ascending
+    const int db = r[1] ^ r[0], dc = r[2] ^ r[0];
+    if ((db != 1 && db != 2 && db != 4) || (dc != 1 && dc != 2 && dc != 4) || db == dc || (r[3] ^ r[0]) != (db | dc)) return -1;
+    const int rb = db == 1 ? 0 : db == 2 ? 1 : 2, rc = dc == 1 ? 0 : dc == 2 ? 1 : 2, ra = 3 - rb - rc;
+    int raw_axis[3], flip[3];
+    raw_axis[a] = ra;
+    raw_axis[b] = rb;
+    raw_axis[c] = rc;
+    flip[b] = (r[0] >> rb) & 1;
+    flip[c] = (r[0] >> rc) & 1;
+    flip[a] = ((r[0] >> ra) & 1) ^ (1 - s);   // the shared face sits at lattice side 1 - s of the neighbour
+    for (int pi = 0; pi < 6; ++pi)
+      if (kAxisPerm[pi][0] == raw_axis[0] && kAxisPerm[pi][1] == raw_axis[1] && kAxisPerm[pi][2] == raw_axis[2])
+        return 8 * pi + flip[0] + 2 * flip[1] + 4 * flip[2];
+    return -1;
+  };
+  // lattice-frame corner dof of a placed cell
+  auto cdof = [&](int32_t c, int q) { return corner[c][oriented_corner(orient[c], q)]; };
+  // may cell c (with orientation oc) sit at p of component ci?  Every placed cell among the 26
+  // lattice neighbours must share exactly the corner dofs the lattice prescribes.
+  auto fits = [&](int32_t c, int oc, int32_t ci, const std::array<int32_t, 3>& p) {
+    for (int dz = -1; dz <= 1; ++dz)
+      for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 1; ++dx) {
+          if (!dx && !dy && !dz) continue;
+          auto it = at.find({ci, p[0] + dx, p[1] + dy, p[2] + dz});
+          if (it == at.end()) continue;
+          const int32_t o = it->second;
+          const int d[3] = {dx, dy, dz};
+          for (int q = 0; q < 8; ++q) {   // corners of c that lie on the side(s) facing o
+            bool shared = true;
+            int qo = 0;
+            for (int m = 0; m < 3; ++m) {
+              const int bit = (q >> m) & 1;
+              if (d[m] == 1 && !bit) shared = false;
+              if (d[m] == -1 && bit) shared = false;
+              qo |= (d[m] == 0 ? bit : 1 - bit) << m;
+            }
+            if (!shared) continue;
+            if (corner[c][oriented_corner(oc, q)] != cdof(o, qo)) return false;
+          }
+        }
+    return true;
+  };
+
   for (size_t s0 = 0; s0 < ncells; ++s0) {
     const int32_t seed = by_key[s0];
     if (comp[seed] >= 0) continue;
@@ -130,27 +242,41 @@ int build_march_plan(int P, size_t ncells, const int32_t* tdm, int BX, int BY, i
     std::queue<int32_t> q;
     comp[seed] = ci;
     xyz[seed] = {0, 0, 0};
+    orient[seed] = 0;
+    at[{ci, 0, 0, 0}] = seed;
     q.push(seed);
     while (!q.empty()) {
       const int32_t c = q.front();
       q.pop();
       for (int a = 0; a < 3; ++a) lo[a] = std::min(lo[a], xyz[c][a]);
-      for (int f = 0; f < 6; ++f) {
-        const int32_t o = nb[c][f];
-        if (o < 0) continue;
-        std::array<int32_t, 3> want = xyz[c];
-        want[f / 2] += (f & 1) ? 1 : -1;
-        if (comp[o] >= 0) {
-          if (xyz[o] != want) return WF_OK;   // the links close a loop that is not a lattice loop (e.g. periodic)
-          continue;
+      int ra[3], fl[3];
+      orient_decode(orient[c], ra, fl);
+      for (int a = 0; a < 3; ++a)
+        for (int s = 0; s < 2; ++s) {
+          // lattice face (a, s) of c is its raw face (ra[a], s ^ fl[a])
+          const int32_t o = nb[c][2 * ra[a] + (s ^ fl[a])];
+          if (o < 0 || comp[o] >= 0) continue;   // placed cells were checked when they were placed
+          std::array<int32_t, 3> want = xyz[c];
+          want[a] += s ? 1 : -1;
+          if (at.count({ci, want[0], want[1], want[2]})) continue;   // position taken: o starts another component later
+          const int b = (a + 1) % 3 < (a + 2) % 3 ? (a + 1) % 3 : (a + 2) % 3, cc = 3 - a - b;
+          int32_t fd[4];
+          for (int m = 0; m < 4; ++m) fd[m] = cdof(c, (s << a) | ((m & 1) << b) | ((m >> 1) << cc));
+          int oc = orientation_from_face(o, a, s, fd);
+          if (oc < 0 || (!normalise && oc != 0)) continue;
+          if (!fits(o, oc, ci, want)) continue;
+          comp[o] = ci;
+          xyz[o] = want;
+          orient[o] = (uint8_t)oc;
+          at[{ci, want[0], want[1], want[2]}] = o;
+          q.push(o);
         }
-        comp[o] = ci;
-        xyz[o] = want;
-        q.push(o);
-      }
     }
     cmin.push_back(lo);
   }
+  plan->ncomponents = (int)cmin.size();
+  for (size_t c = 0; c < ncells; ++c)
+    if (orient[c] != 0) ++plan->reoriented;
 
   // ---- 3. columns and z segments = work items ----------------------------------
   // Segment length: work items run in rounds of the 512 resident workgroups (2 per CU) and each
@@ -201,10 +327,11 @@ int build_march_plan(int P, size_t ncells, const int32_t* tdm, int BX, int BY, i
     } else
       id = it->second;
     const int slot = (rz % lz) * CB + (ry % BY) * BX + (rx % BX);
-    if (items[id][slot] >= 0) return WF_OK;   // two cells with the same coordinates
+    if (items[id][slot] >= 0) return WF_OK;   // two cells with the same coordinates (cannot happen: placement is injective)
     items[id][slot] = c;
   }
   const size_t nit = items.size();
+  plan->fill = (double)ncells / ((double)nit * slots);
   std::vector<int32_t> item_min(nit, INT32_MAX), order(nit);
   for (size_t b = 0; b < nit; ++b) {
     for (int32_t c : items[b])
@@ -214,6 +341,18 @@ int build_march_plan(int P, size_t ncells, const int32_t* tdm, int BX, int BY, i
   std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return item_min[a] < item_min[b]; });
 
   // ---- 4. dof tiles, conformity check, patterns -----------------------------------
+  // raw tensor index of the lattice-frame node (i, j, k) for each orientation in use
+  std::vector<std::vector<int32_t>> lmap(48);
+  auto local_map = [&](int code) -> const std::vector<int32_t>& {
+    auto& m = lmap[code];
+    if (m.empty()) {
+      m.resize(nd);
+      for (int k = 0; k < n; ++k)
+        for (int j = 0; j < n; ++j)
+          for (int i = 0; i < n; ++i) m[i + n * (j + n * k)] = orient_local_index(code, n, i, j, k);
+    }
+    return m;
+  };
   const size_t tsize = (size_t)(P * lz + 1) * TP;
   plan->tile_size = (int)tsize;
   plan->slot_cell.assign(nit * slots, -1);
@@ -236,17 +375,18 @@ int build_march_plan(int P, size_t ncells, const int32_t* tdm, int BX, int BY, i
           if (c < 0) continue;
           layers = l + 1;
           const int32_t* d = tdm + (size_t)c * nd;
+          const std::vector<int32_t>& lm = local_map(orient[c]);
           for (int k = 0; k < n; ++k)
             for (int j = 0; j < n; ++j)
               for (int i = 0; i < n; ++i) {
                 int32_t& slot = tile[(size_t)(P * l + k) * TP + (P * ly + j) * TX + (P * lx + i)];
-                const int32_t dof = d[i + n * (j + n * k)];
+                const int32_t dof = d[lm[i + n * (j + n * k)]];
                 if (slot >= 0 && slot != dof) return WF_OK;   // the cells of the column do not conform on the tile
                 slot = dof;
               }
         }
-    // a dof must not sit at two positions of the tile (its contributions would be added twice in
-    // different flushes -- harmless -- but its x value is simply read twice; allowed)
+    // (a dof may sit at two positions of the tile -- around an irregular edge, or on a periodic mesh
+    // one column wide: its x value is read twice and its contributions reach y in two atomics)
     const int32_t base = item_min[order[ob]];
     for (auto& v : tile)
       if (v >= 0) v -= base;

@@ -154,8 +154,12 @@ __global__ void k_geometry_hex(int n, int CB, int ncells, const double* __restri
 
 // the same for a subset of slots of the blocked layout: cell c of the list goes to slot slot_of[c]
 // (batch = slot / CB); used by the indexed marching operator, whose slot array has gaps
+// cell_sign (may be null): -1 for cells whose vertices were handed over in a reflected frame (lattice
+// plan, generic_plan.cpp).  G = K K^T |det J| w does not depend on the frame; without the fabs
+// (spectral_mass.hpp:58-64) det J changes sign under a reflection and is corrected here.
 __global__ void k_geometry_hex_slots(int n, int CB, int ncells, const double* __restrict__ xverts,
                                      const int32_t* __restrict__ geom_dofmap, const int32_t* __restrict__ slot_of,
+                                     const int8_t* __restrict__ cell_sign,
                                      const double* __restrict__ pts, const double* __restrict__ wts, int use_fabs,
                                      int do_clamp, double* __restrict__ G6blk)
 {
@@ -173,6 +177,8 @@ __global__ void k_geometry_hex_slots(int n, int CB, int ncells, const double* __
   }
   double G9[9], d;
   hex_point_geometry(xv, pts[i], pts[j], pts[k], wts[i] * wts[j] * wts[k], use_fabs, do_clamp, G9, &d);
+  if (!use_fabs && cell_sign && cell_sign[c] < 0)
+    for (int m = 0; m < 9; ++m) G9[m] = -G9[m];
   const int slot = slot_of[c];
   store_g6(G6blk, n, CB * n * n, slot / CB, k, (slot % CB) * n * n + j * n + i, G9);
 }
@@ -834,8 +840,12 @@ int launch_mass_dense_col(int P, int ncells, const int32_t* d_uoff, const int32_
 // 1 = no scatter, 2 = geometry served from L2, 4 = no x gather, 8 = no contractions.
 static int ablate_flags()
 {
+#ifdef WF_DIAG
   const char* e = std::getenv("WF_ABLATE");
   return e ? std::atoi(e) : 0;
+#else
+  return 0;
+#endif
 }
 
 static inline unsigned grid_for(size_t n, unsigned block) { return (unsigned)((n + block - 1) / block); }
@@ -862,25 +872,26 @@ int launch_geometry_hex(int P, int ncells, const double* d_xverts, const int32_t
   return WF_OK;
 }
 
-int launch_geometry_hex_slots(int P, int ncells, const double* d_xverts, const int32_t* d_geom_dofmap,
-                              const int32_t* d_slot_of, const double* d_pts, const double* d_wts, int use_fabs,
-                              int clamp, double* d_G6blk, hipStream_t s)
+int launch_geometry_hex_slots(int P, int CB, int ncells, const double* d_xverts, const int32_t* d_geom_dofmap,
+                              const int32_t* d_slot_of, const uint8_t* d_sign, const double* d_pts, const double* d_wts,
+                              int use_fabs, int clamp, double* d_G6blk, hipStream_t s)
 {
   const int n = P + 1;
   const size_t N = (size_t)ncells * n * n * n;
   if (N == 0) return WF_OK;
-  hipLaunchKernelGGL(k_geometry_hex_slots, dim3(grid_for(N, 256)), dim3(256), 0, s, n, cells_per_batch(P), ncells,
-                     d_xverts, d_geom_dofmap, d_slot_of, d_pts, d_wts, use_fabs, clamp, d_G6blk);
+  hipLaunchKernelGGL(k_geometry_hex_slots, dim3(grid_for(N, 256)), dim3(256), 0, s, n, CB, ncells,
+                     d_xverts, d_geom_dofmap, d_slot_of, reinterpret_cast<const int8_t*>(d_sign), d_pts, d_wts, use_fabs,
+                     clamp, d_G6blk);
   WF_LAUNCH_CHECK();
   return WF_OK;
 }
 
-int launch_pack_G6(int P, int ncells, const double* d_G9, double* d_G6blk, hipStream_t s)
+int launch_pack_G6(int P, int CB, int ncells, const double* d_G9, double* d_G6blk, hipStream_t s)
 {
   const int n = P + 1;
   const size_t N = (size_t)ncells * n * n * n;
   if (N == 0) return WF_OK;
-  hipLaunchKernelGGL(k_pack_G6, dim3(grid_for(N, 256)), dim3(256), 0, s, n, cells_per_batch(P), ncells, d_G9,
+  hipLaunchKernelGGL(k_pack_G6, dim3(grid_for(N, 256)), dim3(256), 0, s, n, CB, ncells, d_G9,
                      d_G6blk);
   WF_LAUNCH_CHECK();
   return WF_OK;
@@ -1027,9 +1038,7 @@ int launch_mass_lumped_u(int ncells, int nd, int CB, const int32_t* d_uoff, cons
 // lanes (measured: P2 >= 8, P4 2..8, P6 4)
 int mass_dense_cells_per_batch(int mx)
 {
-  int CB = std::max(1, std::min(1400 / (mx * mx * mx), 32));
-  if (const char* e = std::getenv("WF_MASS_CB")) CB = std::max(1, std::atoi(e));   // tuning hook
-  return CB;
+  return std::max(1, std::min(1400 / (mx * mx * mx), 32));
 }
 
 int launch_mass_dense(int P, int nq1, int ncells, const int32_t* d_dofmap, const int32_t* d_uoff,

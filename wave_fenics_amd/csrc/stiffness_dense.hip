@@ -531,12 +531,17 @@ static int launch_dense_t(const DenseOpData* d, double coeff, int do_clamp, cons
   if (lds > 64 * 1024)
     WF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds));
-  const int wgs_per_cu = std::getenv("WF_DENSE_WGS") ? std::atoi(std::getenv("WF_DENSE_WGS")) : 2;   // diagnostic override
+#ifdef WF_DIAG   // diagnostic overrides, compiled in by tools/diag_build.sh only
+  const int wgs_per_cu = std::getenv("WF_DENSE_WGS") ? std::atoi(std::getenv("WF_DENSE_WGS")) : 2;
+  const int ablate = std::getenv("WF_ABLATE") ? std::atoi(std::getenv("WF_ABLATE")) : 0;
+  const int stagger = std::getenv("WF_DENSE_STAGGER") ? std::atoi(std::getenv("WF_DENSE_STAGGER")) : 0;
+#else
+  const int wgs_per_cu = 2, ablate = 0, stagger = 0;
+#endif
   const unsigned nb = (unsigned)std::min(d->nbatch, 256 * wgs_per_cu);   // persistent: the table is staged into LDS once per workgroup
   hipLaunchKernelGGL(kern, dim3(nb), dim3(64 * NW), lds, s, d->nd, d->nq, d->nbatch, d->numax, d->d_T, d->d_w, d->d_C,
                      d->d_locP, d->d_uoff, d->d_uniq, d->d_clampb, coeff, do_clamp, d_x, d_y,
-                     std::getenv("WF_ABLATE") ? std::atoi(std::getenv("WF_ABLATE")) : 0,
-                     std::getenv("WF_DENSE_STAGGER") ? std::atoi(std::getenv("WF_DENSE_STAGGER")) : 0);
+                     ablate, stagger);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     set_error(std::string("stiffness_dense launch failed: ") + hipGetErrorString(e));

@@ -292,8 +292,12 @@ __global__ __launch_bounds__(256, (P <= 4 ? 2 : 1)) void k_stiffness_march(int n
 
 static int march_ablate()
 {
+#ifdef WF_DIAG
   const char* e = std::getenv("WF_ABLATE");
   return e ? std::atoi(e) : 0;
+#else
+  return 0;
+#endif
 }
 
 template <int P, int BX, int BY>

@@ -118,7 +118,8 @@ __global__ __launch_bounds__(256, 2) void k_march_idx(int lz, int tile_size, con
                                                                 const int32_t* __restrict__ pat_off,
                                                                 const void* __restrict__ geom,
                                                                 const double* __restrict__ dD, DMat dm, double coeff,
-                                                                const double* __restrict__ x, double* __restrict__ y)
+                                                                const double* __restrict__ x, double* __restrict__ y,
+                                                                const int32_t* __restrict__ items)
 {
   constexpr int n = P + 1, n2 = n * n, nd = n * n2;
   constexpr int CB = BX * BY, NT = CB * n2;
@@ -136,7 +137,8 @@ __global__ __launch_bounds__(256, 2) void k_march_idx(int lz, int tile_size, con
   extern __shared__ __attribute__((aligned(16))) int32_t sIdx[];     // [(P lz + 1)][TP] dof offsets of the column, -1 = none
 
   const int t = threadIdx.x;
-  const size_t item = blockIdx.x;
+  // work item; an optional item list selects a subset (interior / interface split of the ghost exchange)
+  const size_t item = items ? (size_t)items[blockIdx.x] : (size_t)blockIdx.x;
   const int nl = item_layers[item];
   const size_t gbase = (size_t)item_base[item];
   const int32_t* __restrict__ pat = pat_off + (size_t)item_pattern[item] * tile_size;
@@ -327,19 +329,19 @@ __global__ __launch_bounds__(256, 2) void k_march_idx(int lz, int tile_size, con
 
 template <int OP, int P, int BX, int BY>
 static int launch_t(const MarchPlanDev& pd, const double* d_G6blk, const double* d_D, const DMat& dm, double coeff,
-                    const double* d_x, double* d_y, hipStream_t s)
+                    const double* d_x, double* d_y, const int32_t* d_items, int nitems, hipStream_t s)
 {
-  if (pd.nitems == 0) return WF_OK;
+  const int nwg = d_items ? nitems : pd.nitems;
+  if (nwg == 0) return WF_OK;
   const size_t dyn = (size_t)pd.tile_size * sizeof(int32_t);
-  static size_t dyn_set = 0;   // per instantiation: static + dynamic LDS may exceed the 64 KB default limit
-  if (dyn > dyn_set) {
-    WF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_march_idx<OP, P, BX, BY>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
-    dyn_set = dyn;
-  }
-  hipLaunchKernelGGL((k_march_idx<OP, P, BX, BY>), dim3((unsigned)pd.nitems), dim3(256), dyn, s, pd.lz, pd.tile_size,
+  // static + dynamic LDS may exceed the 64 KB default limit.  The attribute is per device; it is set on
+  // every launch (a cheap host call) instead of being cached in a process-wide static, which a second
+  // device or a concurrent first launch from another host thread would not see.
+  WF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_march_idx<OP, P, BX, BY>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+  hipLaunchKernelGGL((k_march_idx<OP, P, BX, BY>), dim3((unsigned)nwg), dim3(256), dyn, s, pd.lz, pd.tile_size,
                      pd.d_item_base, pd.d_item_pattern, pd.d_item_layers, pd.d_pat_off,
-                     static_cast<const void*>(d_G6blk), d_D, dm, coeff, d_x, d_y);
+                     static_cast<const void*>(d_G6blk), d_D, dm, coeff, d_x, d_y, d_items);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     set_error(std::string("stiffness_march_idx launch failed: ") + hipGetErrorString(e));
@@ -348,24 +350,42 @@ static int launch_t(const MarchPlanDev& pd, const double* d_G6blk, const double*
   return WF_OK;
 }
 
-// static LDS of the kernel + the index tile must leave room for two workgroups per CU
-size_t march_idx_lds_bytes(int P, int BX, int BY, int lz)
+// the cross-sections with BX * BY == floor(256 / n^2) cells (geometry batch layout)
+void march_idx_shape(int kind, int P, int* bx, int* by)
 {
+  static const int kBX[8] = {0, 8, 7, 4, 5, 7, 5, 2}, kBY[8] = {0, 8, 4, 4, 2, 1, 1, 2};
+  *bx = kBX[P];
+  *by = kBY[P];
+  if (kind == OP_KIND_STIFFNESS && P >= 5) march_ks_shape(P, bx, by);
+}
+
+// LDS of one workgroup: the kernel's static arrays + the index tile
+size_t march_idx_lds_bytes(int kind, int P, int BX, int BY, int lz)
+{
+  if (kind == OP_KIND_STIFFNESS && P >= 5) return march_ks_lds_bytes(P, BX, BY, lz, true);
   const int n = P + 1, n2 = n * n, nd = n * n2, CB = BX * BY, TP = (P * BX + 1) * (P * BY + 1);
   return (size_t)((P + 1) * TP + CB * P * n2 + 2 * CB * nd + n * n) * sizeof(double) + (size_t)(P * lz + 1) * TP * sizeof(int32_t);
 }
 
-int launch_stiffness_march_idx(int P, int variant, const MarchPlanDev& pd, const double* d_G6blk, const double* d_D,
-                               const DMat& dm, double coeff, const double* d_x, double* d_y, hipStream_t s)
+// two workgroups per CU for the 256-thread kernels, one 512-thread workgroup for the k-split kernel
+size_t march_idx_lds_budget(int kind, int P)
 {
-  (void)variant;
-  switch (P) {   // the cross-sections with BX * BY == floor(256 / n^2) cells (geometry batch layout)
-    case 1: return launch_t<OP_STIFFNESS, 1, 8, 8>(pd, d_G6blk, d_D, dm, coeff, d_x, d_y, s);
-    case 2: return launch_t<OP_STIFFNESS, 2, 7, 4>(pd, d_G6blk, d_D, dm, coeff, d_x, d_y, s);
-    case 3: return launch_t<OP_STIFFNESS, 3, 4, 4>(pd, d_G6blk, d_D, dm, coeff, d_x, d_y, s);
-    case 4: return launch_t<OP_STIFFNESS, 4, 5, 2>(pd, d_G6blk, d_D, dm, coeff, d_x, d_y, s);
+  return (kind == OP_KIND_STIFFNESS && P >= 5) ? (size_t)158 * 1024 : (size_t)80 * 1024;
+}
+
+int launch_stiffness_march_idx(int P, const MarchPlanDev& pd, const double* d_G6blk, const double* d_D,
+                               const DMat& dm, double coeff, const double* d_x, double* d_y, const int32_t* d_items,
+                               int nitems, hipStream_t s)
+{
+  switch (P) {
+    case 1: return launch_t<OP_STIFFNESS, 1, 8, 8>(pd, d_G6blk, d_D, dm, coeff, d_x, d_y, d_items, nitems, s);
+    case 2: return launch_t<OP_STIFFNESS, 2, 7, 4>(pd, d_G6blk, d_D, dm, coeff, d_x, d_y, d_items, nitems, s);
+    case 3: return launch_t<OP_STIFFNESS, 3, 4, 4>(pd, d_G6blk, d_D, dm, coeff, d_x, d_y, d_items, nitems, s);
+    case 4: return launch_t<OP_STIFFNESS, 4, 5, 2>(pd, d_G6blk, d_D, dm, coeff, d_x, d_y, d_items, nitems, s);
+    case 5: case 6: case 7:
+      return launch_stiffness_march_ks_idx(P, pd, d_G6blk, d_D, dm, coeff, d_x, d_y, d_items, nitems, s);
   }
-  set_error("stiffness_march_idx: compiled for degrees 1..4");
+  set_error("stiffness_march_idx: degree must be 1..7");
   return WF_ERR_UNSUPPORTED;
 }
 
@@ -374,13 +394,13 @@ int launch_mass_march_idx(int P, const MarchPlanDev& pd, const double* d_detJblk
                           const double* d_x, double* d_y, hipStream_t s)
 {
   switch (P) {
-    case 1: return launch_t<OP_MASS, 1, 8, 8>(pd, d_detJblk, d_phi1, pm, 0.0, d_x, d_y, s);
-    case 2: return launch_t<OP_MASS, 2, 7, 4>(pd, d_detJblk, d_phi1, pm, 0.0, d_x, d_y, s);
-    case 3: return launch_t<OP_MASS, 3, 4, 4>(pd, d_detJblk, d_phi1, pm, 0.0, d_x, d_y, s);
-    case 4: return launch_t<OP_MASS, 4, 5, 2>(pd, d_detJblk, d_phi1, pm, 0.0, d_x, d_y, s);
-    case 5: return launch_t<OP_MASS, 5, 7, 1>(pd, d_detJblk, d_phi1, pm, 0.0, d_x, d_y, s);
-    case 6: return launch_t<OP_MASS, 6, 5, 1>(pd, d_detJblk, d_phi1, pm, 0.0, d_x, d_y, s);
-    case 7: return launch_t<OP_MASS, 7, 2, 2>(pd, d_detJblk, d_phi1, pm, 0.0, d_x, d_y, s);
+    case 1: return launch_t<OP_MASS, 1, 8, 8>(pd, d_detJblk, d_phi1, pm, 0.0, d_x, d_y, nullptr, 0, s);
+    case 2: return launch_t<OP_MASS, 2, 7, 4>(pd, d_detJblk, d_phi1, pm, 0.0, d_x, d_y, nullptr, 0, s);
+    case 3: return launch_t<OP_MASS, 3, 4, 4>(pd, d_detJblk, d_phi1, pm, 0.0, d_x, d_y, nullptr, 0, s);
+    case 4: return launch_t<OP_MASS, 4, 5, 2>(pd, d_detJblk, d_phi1, pm, 0.0, d_x, d_y, nullptr, 0, s);
+    case 5: return launch_t<OP_MASS, 5, 7, 1>(pd, d_detJblk, d_phi1, pm, 0.0, d_x, d_y, nullptr, 0, s);
+    case 6: return launch_t<OP_MASS, 6, 5, 1>(pd, d_detJblk, d_phi1, pm, 0.0, d_x, d_y, nullptr, 0, s);
+    case 7: return launch_t<OP_MASS, 7, 2, 2>(pd, d_detJblk, d_phi1, pm, 0.0, d_x, d_y, nullptr, 0, s);
   }
   set_error("mass_march_idx: degree must be 1..7");
   return WF_ERR_UNSUPPORTED;

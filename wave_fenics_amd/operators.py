@@ -130,23 +130,59 @@ def precompute_geometric_data(mesh, p: int, use_fabs: bool = True, clamp: bool =
 # ---------------------------------------------------------------------------
 # operator handles
 # ---------------------------------------------------------------------------
+def make_tuning(tuning) -> "_lib.Tuning | None":
+    """wf_tuning from a dict (kernel=, variant=, lz=, lz0=, block=(bx, by, bz), keep_cell_order=, orient=) or None.
+    `kernel` is a WF_KERNEL_FORCE_* value or one of "batch", "box_block", "mass_any", "elementwise", "march"."""
+    if tuning is None:
+        return None
+    if isinstance(tuning, _lib.Tuning):
+        return tuning
+    names = {"auto": 0, "batch": _lib.WF_KERNEL_FORCE_BATCH, "box_block": _lib.WF_KERNEL_FORCE_BOX_BLOCK,
+             "mass_any": _lib.WF_KERNEL_FORCE_MASS_ANY, "elementwise": _lib.WF_KERNEL_FORCE_ELEMENTWISE,
+             "march": _lib.WF_KERNEL_FORCE_MARCH}
+    t = _lib.Tuning()
+    k = tuning.get("kernel", 0)
+    t.kernel = names[k] if isinstance(k, str) else int(k)
+    t.variant = int(tuning.get("variant", -1)) + 1       # C ABI: compiled cross-section + 1, 0 = default
+    t.lz = int(tuning.get("lz", 0))
+    t.lz0 = int(tuning.get("lz0", 0))
+    t.bx, t.by, t.bz = (int(v) for v in tuning.get("block", (0, 0, 0)))
+    t.keep_cell_order = int(bool(tuning.get("keep_cell_order", False)))
+    t.orient = int(tuning.get("orient", 0))
+    return t
+
+
+KERNEL_NAMES = {0: "none", 1: "march_box", 2: "march_idx", 3: "batch_unique", 4: "box_block", 5: "diagonal",
+                6: "mass_dense_any", 7: "dense_simplex", 8: "elementwise"}
+
+
 class _Operator:
     _kind = None
 
     def __init__(self):
         self._h = c_void_p()
 
-    def _create(self, desc: OpDesc, keep=()):
+    def _create(self, desc: OpDesc, keep=(), tuning=None):
         self._keep = keep
+        t = make_tuning(tuning)
+        if t is not None:
+            desc.tuning = ctypes.pointer(t)
         check(lib().wf_op_create(ctypes.byref(desc), ctypes.byref(self._h)))
         self._keep = ()
         self._info()
 
-    def _create_box(self, kind: int, p: int, mesh, c0: float, flags: int):
+    def _create_box(self, kind: int, p: int, mesh, c0: float, flags: int, tuning=None):
         nx, ny, nz = mesh.n
         x = np.ascontiguousarray(mesh.x, dtype=np.float64)
-        check(lib().wf_op_create_box(kind, p, nx, ny, nz, _dp(x), float(c0), flags, ctypes.byref(self._h)))
+        t = make_tuning(tuning)
+        check(lib().wf_op_create_box_tuned(kind, p, nx, ny, nz, _dp(x), float(c0), flags,
+                                           ctypes.byref(t) if t is not None else None, ctypes.byref(self._h)))
         self._info()
+
+    @property
+    def kernel(self) -> str:
+        """Name of the kernel wf_op_apply launches (wf_op_info_t.kernel)."""
+        return KERNEL_NAMES.get(self.info.kernel, "?")
 
     def _info(self):
         info = OpInfo()
@@ -171,9 +207,21 @@ class _Operator:
 
     def set_ghost_faces(self, gx: bool, gy: bool, gz: bool) -> bool:
         """Declare which lower lattice planes are ghost planes (domain
-        decomposition).  Returns False when this operator cannot be split (generic
-        dofmap kernels): the caller then uses the unsplit sequence."""
+        decomposition, box operators).  Returns False when this operator cannot be
+        split this way: the caller then uses set_ghost_dofs or the unsplit sequence."""
         rc = lib().wf_op_set_ghost_faces(self._h, int(gx), int(gy), int(gz))
+        if rc == -2:
+            return False
+        check(rc)
+        self._info()
+        return True
+
+    def set_ghost_dofs(self, ghost_positions) -> bool:
+        """Interior / interface split from the ghost positions of the local array (the
+        list the VectorUpdater unpacks into): works for every marching operator, box or
+        arbitrary dofmap.  Returns False for operators that run a batch kernel."""
+        g = np.ascontiguousarray(ghost_positions, dtype=np.int32)
+        rc = lib().wf_op_set_ghost_dofs(self._h, _ip(g) if g.size else None, int(g.size))
         if rc == -2:
             return False
         check(rc)
@@ -247,7 +295,7 @@ class StiffnessOperator(_Operator):
     (arbitrary dofmap, atomic scatter) kernel."""
 
     def __init__(self, V: FunctionSpace, bdegree: int, params: dict | None = None, G=None, perm=None,
-                 structured: bool | None = None, flags: int = 0):
+                 structured: bool | None = None, flags: int = 0, tuning=None):
         super().__init__()
         c0 = 1500.0 if not params else float(params.get("c0", 1500.0))
         self.c0 = c0
@@ -256,7 +304,7 @@ class StiffnessOperator(_Operator):
         if structured:
             if bdegree != V.degree:
                 raise _lib.WavehipError("structured operator: bdegree must equal the space's degree")
-            self._create_box(_lib.WF_OP_STIFFNESS, bdegree, V.mesh, c0, flags)
+            self._create_box(_lib.WF_OP_STIFFNESS, bdegree, V.mesh, c0, flags, tuning)
             return
         d, keep = _base_desc(V, _lib.WF_OP_STIFFNESS, bdegree, perm)
         d.c0 = c0
@@ -269,7 +317,7 @@ class StiffnessOperator(_Operator):
             d.h_G = _dp(Gc)
         else:
             _attach_mesh(d, V, keep)
-        self._create(d, keep)
+        self._create(d, keep, tuning)
 
 
 class MassOperatorLumped(_Operator):
@@ -277,7 +325,7 @@ class MassOperatorLumped(_Operator):
     mass y += M x.  detJ = |det J| w (fabs), as precompute_geometric_data."""
 
     def __init__(self, V: FunctionSpace, bdegree: int, detJ=None, perm=None, structured: bool | None = None,
-                 flags: int = 0):
+                 flags: int = 0, tuning=None):
         super().__init__()
         if structured is None:
             structured = bool(getattr(V, "structured", False)) and detJ is None and perm is None
@@ -292,7 +340,7 @@ class MassOperatorLumped(_Operator):
             d.h_detJ = _dp(Dc)
         else:
             _attach_mesh(d, V, keep)
-        self._create(d, keep)
+        self._create(d, keep, tuning)
 
 
 class SpectralMassOperator(MassOperatorLumped):
@@ -319,7 +367,7 @@ class MassOperator(_Operator):
     explicit tables: `phi1` [nq1][P+1] and `detJ` [ncells][nq1^3] (mass.hpp:35-39)."""
 
     def __init__(self, V: FunctionSpace, degree: int, phi1: np.ndarray | None = None, detJ: np.ndarray | None = None,
-                 perm=None, variant: str = "gll_warped", quad: str = "gll", qdegree: int | None = None):
+                 perm=None, variant: str = "gll_warped", quad: str = "gll", qdegree: int | None = None, tuning=None):
         super().__init__()
         d, keep = _base_desc(V, _lib.WF_OP_MASS_DENSE, degree, perm)
         if phi1 is None:
@@ -344,10 +392,11 @@ class MassOperator(_Operator):
             if not hasattr(self, "points1"):
                 raise _lib.WavehipError("MassOperator: explicit phi1 needs detJ")
             _attach_mesh(d, V, keep)
+            d.flags |= _lib.WF_FLAG_NO_FABS   # mass.hpp:35-39: det J * w keeps its sign (compute_jacobian_determinant)
             qp, qw = np.ascontiguousarray(self.points1), np.ascontiguousarray(self.weights1)
             keep += [qp, qw]
             d.h_qpts1, d.h_qwts1 = _dp(qp), _dp(qw)
-        self._create(d, keep)
+        self._create(d, keep, tuning)
 
 
 # ---------------------------------------------------------------------------
