@@ -80,6 +80,9 @@ def main():
     ap.add_argument("--degree", type=int, default=4, help="element degree (reference flag --degree)")
     ap.add_argument("--generic", action="store_true", help="use the arbitrary-dofmap kernel instead of the box kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--variant", type=int, default=-1, help="tuning: compiled cross-section of the one-thread-per-column "
+                    "marching kernel (0..2); default: the library's choice")
+    ap.add_argument("--block", default="", help="tuning: column cross-section bx,by of the k-split marching kernel")
     ap.add_argument("--cpu-sample", type=int, default=24)
     ap.add_argument("--periodic", default="", help="axes (e.g. xyz) whose opposite faces are identified: every rank "
                     "then has ghost planes on those axes and exchanges them over RCCL -- with one rank, with itself "
@@ -163,7 +166,13 @@ def main():
         parallelism = (f"dd{world} ({part.procs[0]}x{part.procs[1]}x{part.procs[2]}), exchange={updater.transport}"
                        + (f", periodic={args.periodic}" if any(periodic) else ""))
 
-    K = w.StiffnessOperator(V, p, {"c0": 1500.0})
+    tuning = None
+    if args.variant >= 0 or args.block:
+        tuning = {"variant": args.variant}
+        if args.block:
+            bx, by = (int(v) for v in args.block.split(","))
+            tuning["block"] = (bx, by, 1)
+    K = w.StiffnessOperator(V, p, {"c0": 1500.0}, tuning=tuning)
     M = w.MassOperatorLumped(V, p)
     N = V.ndofs
     # synthetic input x = sin(2 pi X) at the dof coordinate (demo/gpu_operator/main.cpp:81), built on device

@@ -122,14 +122,22 @@ def test_stiffness_box_block_vs_oracle(gpu, oracle, p, n, block):
     (1, (9, 9, 5), 0, 2), (1, (5, 4, 3), 1, 1), (1, (17, 5, 4), 2, 3),
     (2, (7, 6, 5), 0, 2), (2, (4, 4, 4), 1, 3), (2, (8, 5, 3), 2, 2),
     (3, (5, 5, 4), 0, 3), (3, (4, 4, 3), 1, 2), (3, (5, 3, 3), 2, 1),
+    (4, (7, 5, 6), 3, 2), (4, (11, 2, 5), 3, 4),
     (5, (4, 3, 3), 0, 2), (5, (3, 3, 2), 1, 1), (5, (8, 2, 2), 2, 2),
     (6, (3, 3, 3), 0, 2), (6, (6, 2, 2), 1, 1), (6, (4, 2, 2), 2, 3),
     (7, (3, 3, 2), 0, 1), (7, (5, 2, 2), 1, 2), (7, (3, 2, 3), 2, 2)])
 def test_stiffness_march_vs_oracle(gpu, oracle, p, n, variant, lz):
-    """The production box kernels (marching columns; the k-split form at P >= 5, which has one
-    cross-section per degree): every compiled column cross-section, partial columns at the mesh
-    end, z segments of 1..all layers, accumulate semantics."""
+    """The production box kernels (marching columns): every compiled column cross-section of the
+    one-thread-per-column kernel (P <= 4, variants 0..2) and of the k-split kernel (P >= 5, and
+    P4 as variant 3), partial columns at the mesh end, z segments of 1..all layers, accumulate
+    semantics."""
     import wave_fenics_amd as w
+    KS = {4: [(5, 1), (5, 2)], 5: [(3, 1), (7, 1), (2, 1)], 6: [(1, 1), (2, 1), (5, 1)], 7: [(2, 1), (2, 2), (1, 1)]}
+    tune = {"variant": variant}
+    if p >= 5:
+        tune = {"block": KS[p][variant] + (1,)}
+    elif variant == 3:
+        tune = {"variant": 3, "block": KS[p][lz % 2] + (1,)}
     om, mesh, V = make(oracle, n, p)
     K = oracle.StiffnessOperator(om, p)
     rng = np.random.default_rng(2024)
@@ -137,13 +145,13 @@ def test_stiffness_march_vs_oracle(gpu, oracle, p, n, variant, lz):
     y0 = rng.uniform(-1, 1, om.ndofs) * 1e6
     yref = y0.copy()
     K(x, yref)
-    op = w.StiffnessOperator(V, p, {"c0": 1500.0}, structured=True, tuning={"variant": variant, "lz": lz})
+    op = w.StiffnessOperator(V, p, {"c0": 1500.0}, structured=True, tuning=dict(tune, lz=lz))
     assert op.kernel == "march_box" and op.info.plan_lz == lz
     y = dev(y0, gpu)
     op(dev(x, gpu), y)
     assert relerr(y.cpu().numpy(), yref) <= 1e-12
     # default segmentation as well
-    op = w.StiffnessOperator(V, p, {"c0": 1500.0}, structured=True, tuning={"variant": variant})
+    op = w.StiffnessOperator(V, p, {"c0": 1500.0}, structured=True, tuning=tune)
     y = dev(y0, gpu)
     op(dev(x, gpu), y)
     assert relerr(y.cpu().numpy(), yref) <= 1e-12

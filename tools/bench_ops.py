@@ -100,8 +100,9 @@ def main():
         only = [o for o in only if o != "tet"]
         if not only:
             return
-    for p in (2, 4, 6):
-        n = 216 // p
+    degrees = [int(v) for v in os.environ.get("DEGREES", "2,4,6").split(",")]
+    for p in degrees:
+        n = {1: 216, 2: 108, 3: 72, 4: 54, 5: 43, 6: 36, 7: 31}[p]     # ~10.2 M dofs each
         mesh = w.create_box(n)
         V = w.create_functionspace(mesh, p, build_dofmap=True)
         N = V.ndofs
@@ -109,10 +110,13 @@ def main():
         y = torch.zeros(N, dtype=torch.float64, device=dev)
         tag = {"degree": p, "cells": mesh.ncells, "ndofs": N}
         if "stiffness" in only:
-            for structured in (True, False):
-                op = w.StiffnessOperator(V, p, structured=structured)
-                report(f"stiffness P{p} " + ("box-march" if structured else "generic"), timeit(lambda: op(x, y)),
-                       op.alg_bytes(), N, tag)
+            cases = [(True, None), (False, None), (False, {"kernel": "batch"})]
+            if "KS" in os.environ and p <= 4:
+                cases = [(True, None), (True, {"variant": 3})]
+            for structured, tuning in cases:
+                op = w.StiffnessOperator(V, p, structured=structured, tuning=tuning)
+                report(f"stiffness P{p} " + ("box" if structured else "any dofmap") + f" [{op.kernel}]", timeit(lambda: op(x, y)),
+                       op.alg_bytes(), N, dict(tag, kernel=op.kernel, lz=op.info.plan_lz, tuning=str(tuning)))
                 del op
         if "mass" in only:
             op = w.SpectralMassOperator(V, p, structured=False)

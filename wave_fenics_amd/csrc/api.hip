@@ -141,6 +141,8 @@ int build_unique_lists(wf_op* op, size_t ncells, int nd, int CB)
   return WF_OK;
 }
 
+constexpr int kKsVariant = 3;   // wf_tuning.variant - 1 == 3: the k-split marching kernel (stiffness_march_ks.hip)
+
 void default_box_block(int P, const wf_tuning& tun, int* bx, int* by, int* bz)
 {
   switch (P) {
@@ -404,12 +406,12 @@ int wf_op_create(const wf_op_desc* desc, wf_op** out)
       if ((rc = wf_reorder_dofmap(desc->ncells, nd, use_perm, desc->h_dofmap, tdm.data())) != WF_OK) return rc;
       tsrc = tdm.data();
     }
-    int BX, BY;
+    int BX = tun.bx, BY = tun.by;   // stiffness: a compiled cross-section of the k-split kernel, else the default
     march_idx_shape(pkind, P, &BX, &BY);
     const int CB = BX * BY, NTq = CB * n * n;
     // layers per work item: as many as the kernel's LDS budget per workgroup allows, at most 16
     int lz_max = 16;
-    while (lz_max > 1 && march_idx_lds_bytes(pkind, P, BX, BY, lz_max) > march_idx_lds_budget(pkind, P)) --lz_max;
+    while (lz_max > 1 && march_idx_lds_bytes(pkind, P, BX, BY, lz_max) > march_idx_lds_budget(pkind, P, BX, BY)) --lz_max;
     const int use_fabs = (desc->flags & WF_FLAG_NO_FABS) ? 0 : 1;
     const int clamp = (desc->flags & WF_FLAG_NO_CLAMP) ? 0 : 1;
     // A cell may be looked at with an axis reversed only if the 1-D table reads the same backwards,
@@ -431,6 +433,10 @@ int wf_op_create(const wf_op_desc* desc, wf_op** out)
       op->plan.nitems = plan.nitems;
       op->plan.lz = lz;
       op->plan.tile_size = plan.tile_size;
+      op->plan.bx = BX;
+      op->plan.by = BY;
+      op->bx = BX;
+      op->by = BY;
       op->plan_patterns = plan.npatterns;
       op->plan_reoriented = plan.reoriented;
       op->plan_fill = plan.fill;
@@ -455,10 +461,12 @@ int wf_op_create(const wf_op_desc* desc, wf_op** out)
 
       if (plan_stiffness) {
         op->have_plan = 1;
-        std::vector<double> D(n * n);
+        std::vector<double> D(2 * n * n);   // D, then its transpose (scalar-loaded by the k-split kernel)
         gll_derivative_matrix(P, D.data());
+        for (int q = 0; q < n; ++q)
+          for (int a2 = 0; a2 < n; ++a2) D[n * n + a2 * n + q] = D[q * n + a2];
         for (int q = 0; q < n * n; ++q) op->dm.v[q] = D[q];
-        if ((rc = dev_upload(&op->d_D, D.data(), (size_t)n * n, &op->device_bytes)) != WF_OK) return rc;
+        if ((rc = dev_upload(&op->d_D, D.data(), (size_t)2 * n * n, &op->device_bytes)) != WF_OK) return rc;
 
         // geometry in slot order [item][layer][ly][lx]; missing cells stay zero (they contribute nothing)
         const size_t g6 = nslots * nd * 6;
@@ -634,10 +642,12 @@ int wf_op_create(const wf_op_desc* desc, wf_op** out)
     if ((rc = dev_upload(&op->d_dofmap, src, ncells * nd, &op->device_bytes)) != WF_OK) return rc;
   }
 
-  std::vector<double> D(n * n);
+  std::vector<double> D(2 * n * n);   // D, then its transpose (scalar-loaded by the k-split kernel)
   gll_derivative_matrix(P, D.data());
+  for (int q = 0; q < n; ++q)
+    for (int a2 = 0; a2 < n; ++a2) D[n * n + a2 * n + q] = D[q * n + a2];
   for (int q = 0; q < n * n; ++q) op->dm.v[q] = D[q];
-  if ((rc = dev_upload(&op->d_D, D.data(), (size_t)n * n, &op->device_bytes)) != WF_OK) return rc;
+  if ((rc = dev_upload(&op->d_D, D.data(), (size_t)2 * n * n, &op->device_bytes)) != WF_OK) return rc;
 
   const int use_fabs = (desc->flags & WF_FLAG_NO_FABS) ? 0 : 1;
   const int clamp = (desc->flags & WF_FLAG_NO_CLAMP) ? 0 : 1;
@@ -809,11 +819,19 @@ int wf_op_create_box_tuned(int kind, int degree, int nx, int ny, int nz, const d
     op->march = tun.kernel != WF_KERNEL_FORCE_BOX_BLOCK;
     op->kernel_id = op->march ? WF_KERNEL_MARCH_BOX : WF_KERNEL_BOX_BLOCK;
     if (op->march) {
-      static const int kDefaultVariant[8] = {0, 0, 0, 0, 1, 0, 0, 0};   // P4: 5x2 columns (measured fastest)
+      // P <= 4: the one-thread-per-column kernel (stiffness_march.hip), cross-section wf_tuning.variant - 1;
+      // P >= 5: the k-split kernel (stiffness_march_ks.hip), cross-section wf_tuning.bx x by when compiled
+      // (wf_tuning.variant = 4 selects it at P4 as well, for comparisons)
+      static const int kDefaultVariant[8] = {0, 0, 0, 0, 1, kKsVariant, kKsVariant, kKsVariant};   // P4: 5x2 columns
       op->march_variant = tun.variant > 0 ? tun.variant - 1 : kDefaultVariant[P];
-      if (P >= 5) {
-        op->march_variant = 0;
-        march_ks_shape(P, &op->bx, &op->by);
+      if (P >= 5) op->march_variant = kKsVariant;
+      if (op->march_variant == kKsVariant) {
+        op->bx = tun.bx;
+        op->by = tun.by;
+        if (!march_ks_shape(P, &op->bx, &op->by)) {
+          set_error("wf_op_create_box: the k-split kernel is compiled for degrees 4..7");
+          return WF_ERR_UNSUPPORTED;
+        }
       } else if (!march_variant(P, op->march_variant, &op->bx, &op->by)) {
         set_error("wf_op_create_box: wf_tuning.variant out of range");
         return WF_ERR_INVALID;
@@ -829,7 +847,8 @@ int wf_op_create_box_tuned(int kind, int degree, int nx, int ny, int nz, const d
         const int lz = (nz + nseg - 1) / nseg;
         if (lz < 3 && nseg > 1) break;
         const long items = (long)ncols * ((nz + lz - 1) / lz);
-        const long resident = P >= 5 ? 256 : 512;   // workgroups per round: one 512-thread / two 256-thread per CU
+        // workgroups per round
+        const long resident = op->march_variant != kKsVariant ? 512 : march_ks_resident(P, op->bx, op->by);
         const double cost = (double)((items + resident - 1) / resident) * (lz + 1.5);
         if (cost < best - 1e-9) {
           best = cost;
@@ -841,10 +860,12 @@ int wf_op_create_box_tuned(int kind, int degree, int nx, int ny, int nz, const d
   }
   int rc;
 
-  std::vector<double> D(n * n);
+  std::vector<double> D(2 * n * n);   // D, then its transpose (scalar-loaded by the k-split kernel)
   gll_derivative_matrix(P, D.data());
+  for (int q = 0; q < n; ++q)
+    for (int a2 = 0; a2 < n; ++a2) D[n * n + a2 * n + q] = D[q * n + a2];
   for (int q = 0; q < n * n; ++q) op->dm.v[q] = D[q];
-  if ((rc = dev_upload(&op->d_D, D.data(), (size_t)n * n, &op->device_bytes)) != WF_OK) return rc;
+  if ((rc = dev_upload(&op->d_D, D.data(), (size_t)2 * n * n, &op->device_bytes)) != WF_OK) return rc;
 
   Scratch<double> d_x, d_pts, d_wts;
   const size_t nverts = (size_t)(nx + 1) * (ny + 1) * (nz + 1);
@@ -909,8 +930,8 @@ int wf_op_create_dense_simplex(const wf_dense_desc* desc, wf_op** out)
 static int launch_box_march(const wf_op* op, int lz0, const double* d_x, double* d_y, const int32_t* d_items, int nitems,
                             hipStream_t s)
 {
-  if (op->P >= 5)
-    return launch_stiffness_march_ks_box(op->P, op->nx, op->ny, op->nz, op->lz, lz0, op->d_G6blk, op->d_D, op->dm, op->coeff,
+  if (op->march_variant == kKsVariant)
+    return launch_stiffness_march_ks_box(op->P, op->bx, op->by, op->nx, op->ny, op->nz, op->lz, lz0, op->d_G6blk, op->d_D, op->dm, op->coeff,
                                          d_x, d_y, d_items, nitems, s);
   return launch_stiffness_march(op->P, op->march_variant, op->nx, op->ny, op->nz, op->lz, lz0, op->d_G6blk, op->d_D, op->dm,
                                 op->coeff, d_x, d_y, d_items, nitems, s);

@@ -98,7 +98,7 @@ struct MarchPlan {
   std::vector<int32_t> pat_off;         // [npatterns][tile_size] dof - base per tile position, -1 = uncovered
 };
 struct MarchPlanDev {
-  int nitems = 0, lz = 0, tile_size = 0, variant = 0;
+  int nitems = 0, lz = 0, tile_size = 0, bx = 0, by = 0;
   int32_t *d_item_base = nullptr, *d_item_pattern = nullptr, *d_item_layers = nullptr, *d_pat_off = nullptr;
 };
 // cell orientations: lattice axis m of a cell runs along its own axis raw_axis[m], reversed when flip[m]
@@ -109,23 +109,24 @@ int build_march_plan(int P, size_t ncells, const int32_t* tdm, int BX, int BY, i
                      MarchPlan* plan);
 constexpr int OP_KIND_STIFFNESS = 0, OP_KIND_MASS = 1;
 // column cross-section, LDS need and LDS budget (per workgroup) of the indexed marching kernel of (kind, P)
-void march_idx_shape(int kind, int P, int* bx, int* by);
+void march_idx_shape(int kind, int P, int* bx, int* by);   // stiffness: keeps a compiled (*bx, *by) of the k-split kernel
 size_t march_idx_lds_bytes(int kind, int P, int BX, int BY, int lz);
-size_t march_idx_lds_budget(int kind, int P);
+size_t march_idx_lds_budget(int kind, int P, int BX, int BY);
 int launch_mass_march_idx(int P, const MarchPlanDev& pd, const double* d_detJblk, const double* d_phi1, const DMat& pm,
                           const double* d_x, double* d_y, hipStream_t s);
 int launch_stiffness_march_idx(int P, const MarchPlanDev& pd, const double* d_G6blk, const double* d_D,
                                const DMat& dm, double coeff, const double* d_x, double* d_y, const int32_t* d_items,
                                int nitems, hipStream_t s);
-// k-split marching kernel, P = 5..7 (stiffness_march_ks.hip)
-bool march_ks_shape(int P, int* bx, int* by);
+// k-split marching kernel (stiffness_march_ks.hip): the stiffness kernel of every degree
+bool march_ks_shape(int P, int* bx, int* by);   // keeps a compiled (*bx, *by), else sets the degree's default
+int march_ks_resident(int P, int bx, int by);   // workgroups resident on the chip
 size_t march_ks_lds_bytes(int P, int BX, int BY, int lz, bool idx);
-int launch_stiffness_march_ks_box(int P, int nx, int ny, int nz, int lz, int lz0, const double* d_G6blk, const double* d_D,
+int launch_stiffness_march_ks_box(int P, int bx, int by, int nx, int ny, int nz, int lz, int lz0, const double* d_G6blk,
+                                  const double* d_D, const DMat& dm, double coeff, const double* d_x, double* d_y,
+                                  const int32_t* d_items, int nitems, hipStream_t s);
+int launch_stiffness_march_ks_idx(int P, int bx, int by, const MarchPlanDev& pd, const double* d_G6blk, const double* d_D,
                                   const DMat& dm, double coeff, const double* d_x, double* d_y, const int32_t* d_items,
                                   int nitems, hipStream_t s);
-int launch_stiffness_march_ks_idx(int P, const MarchPlanDev& pd, const double* d_G6blk, const double* d_D, const DMat& dm,
-                                  double coeff, const double* d_x, double* d_y, const int32_t* d_items, int nitems,
-                                  hipStream_t s);
 // dense simplex operator (stiffness_dense.hip)
 struct DenseOpData;
 int dense_setup(int nd, int nq, int ncells, int ndofs, const int32_t* dofmap, const double* dphi,

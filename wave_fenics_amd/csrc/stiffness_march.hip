@@ -49,7 +49,7 @@ __device__ unsigned long long g_march_trace[512 * 4 * kMarchTraceIters * kMarchT
 #endif
 
 template <int P, int BX, int BY>
-__global__ __launch_bounds__(256, (P <= 4 ? 2 : 1)) void k_stiffness_march(int nx, int ny, int nz, int lz, int lz0,
+__global__ __launch_bounds__(256, 2) void k_stiffness_march(int nx, int ny, int nz, int lz, int lz0,
                                                             const double2* __restrict__ G6blk,
                                                             const double* __restrict__ dD, DMat dm,
                                                             double coeff, const double* __restrict__ x,
@@ -328,11 +328,11 @@ bool march_variant(int P, int variant, int* bx, int* by)
       {{5, 5}, {3, 3}, {7, 4}},   // P2: 25 / 9 / 28 cells
       {{4, 4}, {3, 3}, {4, 2}},   // P3: 16 / 9 / 8 cells
       {{3, 3}, {5, 2}, {2, 2}},   // P4: 9 / 10 / 4 cells
-      {{3, 2}, {2, 2}, {7, 1}},   // P5: 6 / 4 / 7 cells
-      {{2, 2}, {5, 1}, {3, 1}},   // P6: 4 / 5 / 3 cells
-      {{2, 2}, {4, 1}, {2, 1}},   // P7: 4 / 4 / 2 cells
+      {{0, 0}, {0, 0}, {0, 0}},   // P5..P7: the k-split kernel (stiffness_march_ks.hip); this one ran at one wave per
+      {{0, 0}, {0, 0}, {0, 0}},   // SIMD there (two geometry register sets per column do not fit 256 VGPRs) and
+      {{0, 0}, {0, 0}, {0, 0}},   // measured 0.26-0.51 ms at 10 M dofs against 0.17-0.22 ms
   };
-  if (P < 1 || P > 7 || variant < 0 || variant > 2) return false;
+  if (P < 1 || P > 4 || variant < 0 || variant > 2) return false;
   *bx = tab[P][variant][0];
   *by = tab[P][variant][1];
   return true;
@@ -350,9 +350,6 @@ int launch_stiffness_march(int P, int variant, int nx, int ny, int nz, int lz, i
   WF_MARCH_CASE(2, 0, 5, 5) WF_MARCH_CASE(2, 1, 3, 3) WF_MARCH_CASE(2, 2, 7, 4)
   WF_MARCH_CASE(3, 0, 4, 4) WF_MARCH_CASE(3, 1, 3, 3) WF_MARCH_CASE(3, 2, 4, 2)
   WF_MARCH_CASE(4, 0, 3, 3) WF_MARCH_CASE(4, 1, 5, 2) WF_MARCH_CASE(4, 2, 2, 2)
-  WF_MARCH_CASE(5, 0, 3, 2) WF_MARCH_CASE(5, 1, 2, 2) WF_MARCH_CASE(5, 2, 7, 1)
-  WF_MARCH_CASE(6, 0, 2, 2) WF_MARCH_CASE(6, 1, 5, 1) WF_MARCH_CASE(6, 2, 3, 1)
-  WF_MARCH_CASE(7, 0, 2, 2) WF_MARCH_CASE(7, 1, 4, 1) WF_MARCH_CASE(7, 2, 2, 1)
   set_error("stiffness_march: unsupported degree/variant");
   return WF_ERR_UNSUPPORTED;
 }

@@ -350,40 +350,50 @@ static int launch_t(const MarchPlanDev& pd, const double* d_G6blk, const double*
   return WF_OK;
 }
 
+// the stiffness operator runs the k-split kernel (stiffness_march_ks.hip) at P >= 5
+static bool march_idx_uses_ks(int P) { return P >= 5; }
+
 // the cross-sections with BX * BY == floor(256 / n^2) cells (geometry batch layout)
 void march_idx_shape(int kind, int P, int* bx, int* by)
 {
   static const int kBX[8] = {0, 8, 7, 4, 5, 7, 5, 2}, kBY[8] = {0, 8, 4, 4, 2, 1, 1, 2};
+  if (kind == OP_KIND_STIFFNESS && march_idx_uses_ks(P)) {
+    march_ks_shape(P, bx, by);   // keeps a compiled (*bx, *by), else the degree's default
+    return;
+  }
   *bx = kBX[P];
   *by = kBY[P];
-  if (kind == OP_KIND_STIFFNESS && P >= 5) march_ks_shape(P, bx, by);
 }
 
 // LDS of one workgroup: the kernel's static arrays + the index tile
 size_t march_idx_lds_bytes(int kind, int P, int BX, int BY, int lz)
 {
-  if (kind == OP_KIND_STIFFNESS && P >= 5) return march_ks_lds_bytes(P, BX, BY, lz, true);
+  if (kind == OP_KIND_STIFFNESS && march_idx_uses_ks(P)) return march_ks_lds_bytes(P, BX, BY, lz, true);
   const int n = P + 1, n2 = n * n, nd = n * n2, CB = BX * BY, TP = (P * BX + 1) * (P * BY + 1);
   return (size_t)((P + 1) * TP + CB * P * n2 + 2 * CB * nd + n * n) * sizeof(double) + (size_t)(P * lz + 1) * TP * sizeof(int32_t);
 }
 
-// two workgroups per CU for the 256-thread kernels, one 512-thread workgroup for the k-split kernel
-size_t march_idx_lds_budget(int kind, int P)
+// LDS a workgroup may use so that as many fit a CU as the kernel's registers allow: the dense-mass kernel runs two
+// 256-thread workgroups per CU; the k-split stiffness kernel one 512-thread, two (P >= 5) or three 256-thread ones
+size_t march_idx_lds_budget(int kind, int P, int BX, int BY)
 {
-  return (kind == OP_KIND_STIFFNESS && P >= 5) ? (size_t)158 * 1024 : (size_t)80 * 1024;
+  if (kind != OP_KIND_STIFFNESS || !march_idx_uses_ks(P)) return (size_t)80 * 1024;
+  const int n = P + 1, NTc = BX * BY * n * n, WG = 2 * (((NTc + 63) / 64) * 64);
+  const int per_cu = WG >= 512 ? (P <= 3 ? 2 : 1) : (P <= 4 ? 768 / WG : 512 / WG);
+  return (size_t)158 * 1024 / per_cu;
 }
 
 int launch_stiffness_march_idx(int P, const MarchPlanDev& pd, const double* d_G6blk, const double* d_D,
                                const DMat& dm, double coeff, const double* d_x, double* d_y, const int32_t* d_items,
                                int nitems, hipStream_t s)
 {
+  if (march_idx_uses_ks(P))
+    return launch_stiffness_march_ks_idx(P, pd.bx, pd.by, pd, d_G6blk, d_D, dm, coeff, d_x, d_y, d_items, nitems, s);
   switch (P) {
     case 1: return launch_t<OP_STIFFNESS, 1, 8, 8>(pd, d_G6blk, d_D, dm, coeff, d_x, d_y, d_items, nitems, s);
     case 2: return launch_t<OP_STIFFNESS, 2, 7, 4>(pd, d_G6blk, d_D, dm, coeff, d_x, d_y, d_items, nitems, s);
     case 3: return launch_t<OP_STIFFNESS, 3, 4, 4>(pd, d_G6blk, d_D, dm, coeff, d_x, d_y, d_items, nitems, s);
     case 4: return launch_t<OP_STIFFNESS, 4, 5, 2>(pd, d_G6blk, d_D, dm, coeff, d_x, d_y, d_items, nitems, s);
-    case 5: case 6: case 7:
-      return launch_stiffness_march_ks_idx(P, pd, d_G6blk, d_D, dm, coeff, d_x, d_y, d_items, nitems, s);
   }
   set_error("stiffness_march_idx: degree must be 1..7");
   return WF_ERR_UNSUPPORTED;

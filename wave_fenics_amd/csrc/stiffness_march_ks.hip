@@ -34,6 +34,16 @@ struct KSplit {
 
 // phase 1 of the element kernel for the levels of half H: reference gradient at the points
 // (i, j, k), times G -> Fr, Fs, Ft (LDS, compact cell layout [k][j][i])
+// The z-direction entries of D are wave-uniform (compile-time k).  Up to P4 they are kernel-argument
+// constants that live in SGPRs (DMat by value).  From P5 on the 2 n^2 SGPRs they need exceed what a wave
+// has: the compiler spilled them to VGPR lanes and every use cost two v_readlane (P6: ~1000 v_readlane per
+// kernel).  There they are read from the LDS copy of D instead (every lane the same address: a broadcast
+// read; sD holds D row-major followed by its transpose).  Scalar loads from global memory at the start of
+// each phase were measured and rejected (P4 0.2015 -> 0.266 ms, P6 0.232 -> 0.314 ms): a pending s_load
+// turns every LDS wait of the phase into lgkmcnt(0).
+template <int P>
+constexpr bool ks_dz_from_lds() { return P >= 5; }
+
 template <int P, int H>
 __device__ __forceinline__ void ks_phase1(const double* __restrict__ U, int sk, int sj, double* __restrict__ Fr,
                                           double* __restrict__ Fs, double* __restrict__ Ft,
@@ -55,7 +65,7 @@ __device__ __forceinline__ void ks_phase1(const double* __restrict__ U, int sk, 
     for (int a = 0; a < n; ++a) {
       ur += di[a] * U[k * sk + j * sj + a];
       us += dj[a] * U[k * sk + a * sj + i];
-      ut += dm.v[k * n + a] * ru[a];
+      ut += (ks_dz_from_lds<P>() ? sD[k * n + a] : dm.v[k * n + a]) * ru[a];
     }
     const double2 *gk = g[k - K0];
     const double g00 = gk[0].x, g01 = gk[0].y, g02 = gk[1].x, g11 = gk[1].y, g12 = gk[2].x, g22 = gk[2].y;
@@ -87,7 +97,7 @@ __device__ __forceinline__ void ks_phase2(const double* __restrict__ Fr, const d
     for (int a = 0; a < n; ++a) {
       s += dti[a] * Fr[k * n2 + j * n + a];
       s += dtj[a] * Fs[k * n2 + a * n + i];
-      s += dm.v[a * n + k] * fz[a];
+      s += (ks_dz_from_lds<P>() ? sD[n * n + k * n + a] : dm.v[a * n + k]) * fz[a];   // sD + n^2: transpose of D
     }
     out[k - K0] = s;
   }
@@ -103,15 +113,15 @@ struct KSLayout {
   static constexpr int oO = oUx + 2 * (P + 1) * TP;      // [2][CB P n2]
   static constexpr int oCy = oO + 2 * CB * P * n2;       // [2][NTc]
   static constexpr int oFr = oCy + 2 * NTc;              // [CB nd] x 3
-  static constexpr int oD = oFr + 3 * CB * nd;           // [n n]
-  static constexpr int ndoubles = ((oD + n * n + 1) / 2) * 2;
+  static constexpr int oD = oFr + 3 * CB * nd;           // [2][n n]: D and its transpose
+  static constexpr int ndoubles = ((oD + 2 * n * n + 1) / 2) * 2;
   static_assert(NTc <= 256, "column does not fit two halves of 256 threads");
 };
 
 size_t march_ks_lds_bytes(int P, int BX, int BY, int lz, bool idx)
 {
   const int n = P + 1, n2 = n * n, nd = n * n2, CB = BX * BY, TP = (P * BX + 1) * (P * BY + 1);
-  size_t d = (size_t)2 * (P + 1) * TP + (size_t)2 * CB * P * n2 + (size_t)2 * CB * n2 + (size_t)3 * CB * nd + n * n + 2;
+  size_t d = (size_t)2 * (P + 1) * TP + (size_t)2 * CB * P * n2 + (size_t)2 * CB * n2 + (size_t)3 * CB * nd + 2 * n * n + 2;
   return d * sizeof(double) + (idx ? (size_t)(P * lz + 1) * TP * sizeof(int32_t) : 0);
 }
 
@@ -127,7 +137,7 @@ struct KSArgs {
   // both
   const int32_t* items;   // optional work-item list (interior / interface split)
   const double2* G6blk;
-  const double* dD;
+  const double* dD;       // device: D[q][a] (n x n, row-major) followed by its transpose
   double coeff;
   const double* x;
   double* y;
@@ -212,7 +222,7 @@ __device__ __forceinline__ void ks_march(const KSArgs& a, const DMat& dm, double
   constexpr int G1 = (NK + 1) / 2;
 
   // ---- prologue ---------------------------------------------------------------------------
-  if (t < n * n) sD[t] = a.dD[t];
+  for (int e = t; e < 2 * n * n; e += WG) sD[e] = a.dD[e];
   if constexpr (IDX) {
     const int32_t* __restrict__ pat = a.pat_off + (size_t)a.item_pattern[item] * a.tile_size;
     for (int e = t; e < (P * nl + 1) * TP; e += WG) sIdx[e] = pat[e];
@@ -269,36 +279,57 @@ __device__ __forceinline__ void ks_march(const KSArgs& a, const DMat& dm, double
     }
   };
 
-  // One layer.  b = l & 1 selects the LDS buffers; `gcur` holds the layer's geometry, `gnext`
-  // receives the next layer's.
-  auto layer = [&](double2 (&gcur)[KH][3], double2 (&gnext)[KH][3], int l, int b) {
-    const bool has_next = l + 1 < nl;
-    const double* Ub = Ux + b * (P + 1) * TP;
-    double* Un = Ux + (b ^ 1) * (P + 1) * TP;
-    double* Ob = O + b * (CB * P * n2);
-    // (a) next layer's x planes and the first half of its geometry: in flight during phase 1.  Loads
-    // are unconditional on clamped addresses (a guard is a branch, and at its join the compiler's
-    // wait-count bookkeeping turns conservative); what is live is decided where it is consumed.
-    const int ln = has_next ? l + 1 : l;
-    double xn[NPOS];
+  // x planes 1..P of layer `lt` -> registers (positions outside the tile / dead entries read a valid
+  // dummy address: a guard around a load is a branch, and at its join the compiler's wait-count
+  // bookkeeping turns conservative; what is live is decided where the registers are consumed)
+  double xn[NPOS];
+  auto load_x = [&](int lt) {
 #pragma unroll
     for (int m = 0; m < NPOS; ++m) {
       const int pos = t + WG * m;
       if constexpr (IDX) {
-        const int32_t off = pos < P * TP ? sIdx[(P * ln + 1) * TP + pos] : -1;
+        const int32_t off = pos < P * TP ? sIdx[(P * lt + 1) * TP + pos] : -1;
         xn[m] = a.x[gbase + (off >= 0 ? off : 0)];
       } else {
-        xn[m] = a.x[plane * (size_t)(P * (z0 + ln) + 1) + gbase + (poff[m] >= 0 ? poff[m] : 0)];
+        xn[m] = a.x[plane * (size_t)(P * (z0 + lt) + 1) + gbase + (poff[m] >= 0 ? poff[m] : 0)];
       }
     }
-    if (has_next) load_g(gnext, ln, 0, G1);
+  };
+  // Where the request for the next layer goes (measured per cross-section, cfg-size meshes):
+  //  EARLY: the request for layer l + 2 (x planes, first half of the geometry) right after barrier B of
+  //         layer l, in front of the flush's atomics, into the registers layer l has just finished with --
+  //         loads, stores and atomics retire in issue order (vmcnt), so a load issued BEHIND an atomic
+  //         cannot be waited for without the atomic's round trip, and hipcc makes even the address
+  //         arithmetic of such a load wait for it.  Faster for the 512-thread workgroups (P4 5x2:
+  //         0.241 -> 0.221 ms box, 0.264 -> 0.236 ms indexed);
+  //  LATE : the request for layer l + 1 at the top of layer l.  Shorter register live ranges: faster for the
+  //         small workgroups that run three per CU (P4 5x1: 0.201 vs 0.233 ms, where EARLY spills).
+  constexpr bool EARLY = WG >= 512;
+  if constexpr (EARLY) {   // prefetch for layer 1 (the prologue has loaded layer 0)
+    const int l1 = nl > 1 ? 1 : 0;
+    load_x(l1);
+    if (nl > 1) load_g(gB, 1, 0, G1);
+  }
 
-    // (b) phase 1
+  // One layer.  b = l & 1 selects the LDS buffers; `gcur` holds the layer's geometry, `gnext`
+  // receives the next layer's (second instalment after barrier A).
+  auto layer = [&](double2 (&gcur)[KH][3], double2 (&gnext)[KH][3], int l, int b) {
+    const bool has_next = l + 1 < nl, has_next2 = l + 2 < nl;
+    const double* Ub = Ux + b * (P + 1) * TP;
+    double* Un = Ux + (b ^ 1) * (P + 1) * TP;
+    double* Ob = O + b * (CB * P * n2);
+    const int ln = has_next ? l + 1 : l;
+    if constexpr (!EARLY) {
+      load_x(ln);
+      if (has_next) load_g(gnext, ln, 0, G1);
+    }
+
+    // (a) phase 1
     if (active) ks_phase1<P, H>(Ub + ucell, TP, TX, Fr + cl * nd, Fs + cl * nd, Ft + cl * nd, sD, dm, gcur, a.coeff, i, j);
     __syncthreads();   // barrier A
     if (has_next) load_g(gnext, ln, G1, NK);
 
-    // (c) phase 2; results of planes 0..P-1 -> O, plane P -> carry; the z-shared plane picks up the
+    // (b) phase 2; results of planes 0..P-1 -> O, plane P -> carry; the z-shared plane picks up the
     // carry the upper half left in the previous layer
     if (active) {
       double out[KH];
@@ -312,7 +343,7 @@ __device__ __forceinline__ void ks_march(const KSArgs& a, const DMat& dm, double
           Cy[b * NTc + tc] = out[k - K0];
       }
     }
-    // (d) x planes of the next layer -> the other buffer: plane P of this layer becomes plane 0,
+    // (c) x planes of the next layer -> the other buffer: plane P of this layer becomes plane 0,
     // planes 1..P come from the prefetch (this is the consumer of xn)
     if (has_next) {
 #pragma unroll
@@ -334,6 +365,12 @@ __device__ __forceinline__ void ks_march(const KSArgs& a, const DMat& dm, double
       }
     }
     __syncthreads();   // barrier B
+    // (d) EARLY: request layer l + 2, into the registers this layer is done with
+    if constexpr (EARLY) {
+      const int l2 = has_next2 ? l + 2 : ln;
+      load_x(l2);
+      if (has_next2) load_g(gcur, l2, 0, G1);
+    }
     // (e) flush: runs beside the next layer's phase 1 (no barrier in between)
     flush(Ob, l);
   };
@@ -374,8 +411,13 @@ __device__ __forceinline__ void ks_march(const KSArgs& a, const DMat& dm, double
   }
 }
 
+// waves per SIMD the register allocation aims at: 512-thread workgroups (two waves per SIMD each) run one
+// per CU; 256-thread workgroups (small columns) three per CU
+template <int P, int BX, int BY>
+constexpr int ks_min_waves() { return KSLayout<P, BX, BY>::WG >= 512 ? 2 : (P <= 4 ? 3 : 2); }
+
 template <int P, int BX, int BY, bool IDX>
-__global__ __launch_bounds__((KSLayout<P, BX, BY>::WG)) void k_march_ks(KSArgs a, DMat dm)
+__global__ __launch_bounds__((KSLayout<P, BX, BY>::WG), (ks_min_waves<P, BX, BY>())) void k_march_ks(KSArgs a, DMat dm)
 {
   extern __shared__ __attribute__((aligned(16))) double ks_smem[];
   // the half is wave-uniform (TH is a multiple of 64): a scalar branch picks the specialisation
@@ -403,27 +445,53 @@ static int launch_ks_t(const KSArgs& a, const DMat& dm, int nwg, size_t lds, hip
   return WF_OK;
 }
 
-// column cross-sections of the k-split kernel (BX * BY * n^2 <= 256)
+// Compiled column cross-sections (BX * BY * n^2 <= 256 threads per half); the first entry of a degree is
+// the default.  Small columns give 256-thread workgroups, of which two or three share a CU.
+// (P <= 4 runs the one-thread-per-column kernels: measured equal at P3 / P4 -- cfg2 0.2216 vs 0.2242 ms inside
+// bench.py, 0.2015 vs 0.2003 ms with x and y resident in the Infinity Cache -- and 5 % faster at P2, where
+// the two halves of a k-split column get 2 and 1 levels.  The P4 5x1 / 5x2 cross-sections stay compiled as a
+// tuning option for such comparisons.)
+#define WF_KS_SHAPES(X)                                                                   \
+  X(4, 5, 1) X(4, 5, 2)                                                                   \
+  X(5, 3, 1) X(5, 7, 1) X(5, 2, 1)                                                        \
+  X(6, 1, 1) X(6, 2, 1) X(6, 5, 1)                                                        \
+  X(7, 2, 1) X(7, 2, 2) X(7, 1, 1)
+
 bool march_ks_shape(int P, int* bx, int* by)
 {
-  switch (P) {
-    case 5: *bx = 7; *by = 1; return true;
-    case 6: *bx = 5; *by = 1; return true;
-    case 7: *bx = 2; *by = 2; return true;
+  // keep *bx, *by when they name a compiled cross-section of this degree, else the default
+  int dbx = 0, dby = 0;
+  bool found = false;
+#define X(PP, BXX, BYY)                                  \
+  if (P == PP) {                                         \
+    if (!dbx) { dbx = BXX; dby = BYY; }                  \
+    if (*bx == BXX && *by == BYY) found = true;          \
   }
-  return false;
+  WF_KS_SHAPES(X)
+#undef X
+  if (!dbx) return false;
+  if (!found) {
+    *bx = dbx;
+    *by = dby;
+  }
+  return true;
 }
 
-int launch_stiffness_march_ks_box(int P, int nx, int ny, int nz, int lz, int lz0, const double* d_G6blk, const double* d_D,
-                                  const DMat& dm, double coeff, const double* d_x, double* d_y, const int32_t* d_items,
-                                  int nitems, hipStream_t s)
+// workgroups of the kernel that fit a CU (LDS and register file): the round size of the z segmentation
+int march_ks_resident(int P, int bx, int by)
+{
+  const int n = P + 1, NTc = bx * by * n * n, TH = ((NTc + 63) / 64) * 64, WG = 2 * TH;
+  const int per_cu_regs = WG >= 512 ? (P <= 3 ? 2 : 1) : (P <= 4 ? 768 / WG : 512 / WG);
+  const size_t lds = march_ks_lds_bytes(P, bx, by, 0, false);
+  const int per_cu_lds = (int)std::max<size_t>(1, (size_t)160 * 1024 / lds);
+  return 256 * std::max(1, std::min(per_cu_regs, per_cu_lds));
+}
+
+int launch_stiffness_march_ks_box(int P, int bx, int by, int nx, int ny, int nz, int lz, int lz0, const double* d_G6blk,
+                                  const double* d_D, const DMat& dm, double coeff, const double* d_x, double* d_y,
+                                  const int32_t* d_items, int nitems, hipStream_t s)
 {
   if ((size_t)nx * ny * nz == 0) return WF_OK;
-  int bx, by;
-  if (!march_ks_shape(P, &bx, &by)) {
-    set_error("march_ks: compiled for degrees 5..7");
-    return WF_ERR_UNSUPPORTED;
-  }
   KSArgs a{};
   a.nx = nx; a.ny = ny; a.nz = nz; a.lz = lz; a.lz0 = lz0;
   a.items = d_items;
@@ -433,23 +501,18 @@ int launch_stiffness_march_ks_box(int P, int nx, int ny, int nz, int lz, int lz0
   const int nseg = 1 + (std::max(nz - lz0, 0) + lz - 1) / lz;
   const int nwg = d_items ? nitems : ncols * nseg;
   const size_t lds = march_ks_lds_bytes(P, bx, by, 0, false);
-  switch (P) {
-    case 5: return launch_ks_t<5, 7, 1, false>(a, dm, nwg, lds, s);
-    case 6: return launch_ks_t<6, 5, 1, false>(a, dm, nwg, lds, s);
-    case 7: return launch_ks_t<7, 2, 2, false>(a, dm, nwg, lds, s);
-  }
+#define X(PP, BXX, BYY) \
+  if (P == PP && bx == BXX && by == BYY) return launch_ks_t<PP, BXX, BYY, false>(a, dm, nwg, lds, s);
+  WF_KS_SHAPES(X)
+#undef X
+  set_error("march_ks: cross-section not compiled");
   return WF_ERR_UNSUPPORTED;
 }
 
-int launch_stiffness_march_ks_idx(int P, const MarchPlanDev& pd, const double* d_G6blk, const double* d_D, const DMat& dm,
-                                  double coeff, const double* d_x, double* d_y, const int32_t* d_items, int nitems,
-                                  hipStream_t s)
+int launch_stiffness_march_ks_idx(int P, int bx, int by, const MarchPlanDev& pd, const double* d_G6blk, const double* d_D,
+                                  const DMat& dm, double coeff, const double* d_x, double* d_y, const int32_t* d_items,
+                                  int nitems, hipStream_t s)
 {
-  int bx, by;
-  if (!march_ks_shape(P, &bx, &by)) {
-    set_error("march_ks: compiled for degrees 5..7");
-    return WF_ERR_UNSUPPORTED;
-  }
   KSArgs a{};
   a.lz = pd.lz;
   a.tile_size = pd.tile_size;
@@ -462,11 +525,11 @@ int launch_stiffness_march_ks_idx(int P, const MarchPlanDev& pd, const double* d
   a.dD = d_D; a.coeff = coeff; a.x = d_x; a.y = d_y;
   const int nwg = d_items ? nitems : pd.nitems;
   const size_t lds = march_ks_lds_bytes(P, bx, by, pd.lz, true);
-  switch (P) {
-    case 5: return launch_ks_t<5, 7, 1, true>(a, dm, nwg, lds, s);
-    case 6: return launch_ks_t<6, 5, 1, true>(a, dm, nwg, lds, s);
-    case 7: return launch_ks_t<7, 2, 2, true>(a, dm, nwg, lds, s);
-  }
+#define X(PP, BXX, BYY) \
+  if (P == PP && bx == BXX && by == BYY) return launch_ks_t<PP, BXX, BYY, true>(a, dm, nwg, lds, s);
+  WF_KS_SHAPES(X)
+#undef X
+  set_error("march_ks: cross-section not compiled");
   return WF_ERR_UNSUPPORTED;
 }
 
