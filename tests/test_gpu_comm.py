@@ -185,6 +185,21 @@ def test_periodic_rk4_vs_oracle(gpu, comm, oracle):
         (eqn.rk4_fused if fused else eqn.rk4)(0.0, 20 * dt - 1e-13, dt)
         assert relerr(eqn.u_n.cpu().numpy(), ref.u_n[l2g]) <= 1e-9     # ghosts included (final scatter_fwd)
         assert relerr(eqn.v_n.cpu().numpy(), ref.v_n[l2g]) <= 1e-9
+    # boundary= handed over explicitly as RANK-LOCAL sets (ghost boundary dofs included, rank-local facet
+    # masses): they go through the same accumulate-to-owner step as the tag-derived ones, and
+    # an arbitrary-dofmap space is split by ghost dofs
+    from wave_fenics_amd.linear_gll import facet_lumped_mass
+    tags = boundary_tags(part)
+    sets = (facet_lumped_mass(part.V, tags, 1), facet_lumped_mass(part.V, tags, 2))
+    assert (~part.owned_mask()[sets[1][0]]).any(), "the test needs ghost dofs in the rank-local boundary set"
+    part.V.structured = False
+    eqn = LinearGLLOpt(part.V, p, 1500.0, 0.5e6, 6e4, updater=vu, boundary=sets, device=gpu)
+    assert eqn._split and eqn.stiff_op.kernel == "march_idx"
+    eqn.init()
+    eqn.rk4_fused(0.0, 20 * dt - 1e-13, dt)
+    assert relerr(eqn.u_n.cpu().numpy(), ref.u_n[l2g]) <= 1e-9
+    assert relerr(eqn.v_n.cpu().numpy(), ref.v_n[l2g]) <= 1e-9
+    part.V.structured = True
 
 
 def test_cxx_updater_and_multi_rank_driver(gpu, oracle, tmp_path):

@@ -149,3 +149,39 @@ def test_rk4_from_mesh_file(oracle, tmp_path):
     u, v = eqn.u_n.cpu().numpy(), eqn.v_n.cpu().numpy()
     assert np.abs(u[ib] - ref.u_n[ia]).max() <= 1e-9 * np.abs(ref.u_n).max()
     assert np.abs(v[ib] - ref.v_n[ia]).max() <= 1e-9 * np.abs(ref.v_n).max()
+
+
+
+def test_tag_reader_checks_extents_and_ranges(tmp_path):
+    """wf_mesh_read_tags must not trust the file -- a Values dataset with another element
+    count than the tag topology, or a facet vertex id outside the mesh, is an error, never a buffer
+    overrun; a grid whose geometry lives in another .h5 than its topology is refused.  (The files are
+    doctored by pointing the XDMF text at datasets of a second file written by wf_mesh_write.)"""
+    import wave_fenics_amd as w
+    from wave_fenics_amd import mesh_io
+    mesh = w.create_box((2, 1, 1))
+    one = mesh_io.MeshTags(np.array([[0, 1, 3, 4]], dtype=np.int32), np.array([1], dtype=np.int32))
+    three = mesh_io.MeshTags(np.array([[0, 1, 3, 4], [1, 2, 4, 5], [0, 3, 6, 9]], dtype=np.int32), np.array([1, 2, 2], dtype=np.int32))
+    a, b = str(tmp_path / "a.xdmf"), str(tmp_path / "b.xdmf")
+    mesh_io.write_mesh(a, "planar3d", mesh, "planar3d_boundaries", one)
+    mesh_io.write_mesh(b, "planar3d", mesh, "planar3d_boundaries", three)
+    txt = open(a).read()
+    # (1) Values from the other file: 3 values for 1 tagged facet
+    bad = str(tmp_path / "bad_values.xdmf")
+    open(bad, "w").write(txt.replace("a.h5:/MeshTags/planar3d_boundaries/Values", "b.h5:/MeshTags/planar3d_boundaries/Values"))
+    with pytest.raises(w.WavehipError, match="one value per tagged facet"):
+        mesh_io.read_mesh(bad, "planar3d", "planar3d_boundaries")
+    # (2) a facet vertex id beyond the mesh's vertices
+    big = mesh_io.MeshTags(np.array([[0, 1, 3, 400]], dtype=np.int32), np.array([1], dtype=np.int32))
+    c = str(tmp_path / "c.xdmf")
+    mesh_io.write_mesh(c, "planar3d", mesh, "planar3d_boundaries", big)
+    with pytest.raises(w.WavehipError, match="facet vertex index out of range"):
+        mesh_io.read_mesh(c, "planar3d", "planar3d_boundaries")
+    # (3) geometry in another file than the topology
+    split = str(tmp_path / "split.xdmf")
+    open(split, "w").write(txt.replace("a.h5:/Mesh/planar3d/geometry", "b.h5:/Mesh/planar3d/geometry"))
+    with pytest.raises(w.WavehipError, match="different HDF5 files"):
+        mesh_io.read_mesh(split, "planar3d")
+    # the untouched files still read, and the mesh can be re-read after its tags (the handle reopens the mesh file)
+    m2, t2 = mesh_io.read_mesh(b, "planar3d", "planar3d_boundaries")
+    assert np.array_equal(t2.values, three.values) and np.array_equal(m2.geom_dofmap, mesh.geom_dofmap)

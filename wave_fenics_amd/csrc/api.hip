@@ -394,6 +394,52 @@ int wf_op_create(const wf_op_desc* desc, wf_op** out)
   const bool plan_stiffness = desc->kind == WF_OP_STIFFNESS;
   const bool plan_mass = desc->kind == WF_OP_MASS_DENSE && desc->nq1 == n && desc->h_phi1
                          && (desc->h_detJ || (have_mesh && desc->h_qpts1 && desc->h_qwts1));
+  // Dense mass with a COLLOCATED rule (the quadrature points are the nodes, phi1 = identity: the GLL rule of
+  // demo/gpu_operator_monolithic/main.cpp:94-96 and of LinearGLL): Phi^T D Phi is the diagonal sum_cells det J w.
+  // It is assembled once and applied as y += m .* x (24 B/dof) -- the result of the dense evaluation up to the
+  // rounding of the six identity contractions.  A wf_tuning kernel hint keeps the dense kernels.
+  if (plan_mass && tun.kernel == WF_KERNEL_AUTO && ncells > 0) {
+    bool ident = true;
+    for (int q = 0; q < n && ident; ++q)
+      for (int a2 = 0; a2 < n; ++a2)
+        if (std::abs(desc->h_phi1[q * n + a2] - (q == a2 ? 1.0 : 0.0)) > 1e-14) ident = false;
+    if (ident) {
+      std::vector<double> hd;
+      const double* hsrc = desc->h_detJ;
+      std::vector<int32_t> qm = make_qmap(n);
+      if (!desc->h_detJ) {
+        Scratch<double> d_x, d_qp, d_qw, d_det;
+        Scratch<int32_t> d_gd;
+        hd.resize(ncells * nd);
+        const int use_fabs = (desc->flags & WF_FLAG_NO_FABS) ? 0 : 1;
+        if ((rc = dev_upload(&d_x.p, desc->h_xverts, (size_t)desc->nverts * 3, nullptr)) != WF_OK) return rc;
+        if ((rc = dev_upload(&d_gd.p, desc->h_geom_dofmap, ncells * 8, nullptr)) != WF_OK) return rc;
+        if ((rc = dev_upload(&d_qp.p, desc->h_qpts1, (size_t)n, nullptr)) != WF_OK) return rc;
+        if ((rc = dev_upload(&d_qw.p, desc->h_qwts1, (size_t)n, nullptr)) != WF_OK) return rc;
+        if ((rc = dev_alloc(&d_det.p, ncells * nd, nullptr)) != WF_OK) return rc;
+        if ((rc = launch_geometry_hex(P, desc->ncells, d_x.p, d_gd.p, d_qp.p, d_qw.p, use_fabs, 0, nullptr, nullptr, d_det.p,
+                                      nullptr)) != WF_OK)
+          return rc;
+        WF_HIP_CHECK(hipDeviceSynchronize());
+        WF_HIP_CHECK(hipMemcpy(hd.data(), d_det.p, hd.size() * sizeof(double), hipMemcpyDeviceToHost));
+        hsrc = hd.data();
+        for (int q = 0; q < nd; ++q) qm[q] = q;   // computed in the engine's point order
+      }
+      std::vector<double> md((size_t)desc->ndofs, 0.0);
+      for (size_t c = 0; c < ncells; ++c)
+        for (int l = 0; l < nd; ++l) {
+          const int32_t dof = desc->h_dofmap[c * nd + (use_perm ? use_perm[l] : l)];   // tensor position l of cell c
+          md[dof] += hsrc[c * nd + qm[l]];
+        }
+      if ((rc = dev_upload(&op->d_mdiag, md.data(), md.size(), &op->device_bytes)) != WF_OK) return rc;
+      op->nq1 = n;
+      op->nq = nd;
+      op->kernel_id = WF_KERNEL_DIAGONAL;
+      *out = op.release();
+      return WF_OK;
+    }
+  }
+
   if ((plan_stiffness || plan_mass) && !force_batch && ncells > 0) {
     if (plan_stiffness)
       WF_REQUIRE(desc->h_G || have_mesh, "wf_op_create: stiffness needs h_G or the mesh (h_xverts, h_geom_dofmap)");
@@ -965,6 +1011,7 @@ int wf_op_apply(wf_op* op, const double* d_x, double* d_y, void* stream)
                                     d_y, s);
       return launch_mass_lumped((int64_t)op->ncells * op->nd, op->d_dofmap, op->d_detJ, d_x, d_y, s);
     case WF_OP_MASS_DENSE:
+      if (op->d_mdiag) return wf_pointwise_mult_add(op->ndofs, op->d_mdiag, d_x, d_y, stream);   // collocated rule
       if (op->have_plan == 2)
         return launch_mass_march_idx(op->P, op->plan, op->d_detJ, op->d_phi1, op->dm, d_x, d_y, s);
       if (op->dense_square && op->generic_unique)

@@ -166,7 +166,8 @@ struct Dataset {
 struct wf_mesh_file {
   std::string xml, dir;
   hid_t file = -1;
-  std::string h5name;
+  std::string h5name;      // file currently open
+  std::string meshfile;    // file of the mesh grid's topology / geometry
   std::string topo, geom;
 };
 
@@ -251,6 +252,13 @@ int wf_mesh_open(const char* xdmf_path, const char* grid_name, wf_mesh_file** ou
     wf::set_error("wf_mesh_open: the grid needs <Topology> and <Geometry> with HDF DataItems");
     return WF_ERR_INVALID;
   }
+  // one .h5 per handle: a grid whose geometry lives in another file than its topology is refused, not
+  // silently read from the wrong file
+  if (file2 != file) {
+    wf::set_error("wf_mesh_open: <Topology> and <Geometry> refer to different HDF5 files (" + file + ", " + file2 + ")");
+    return WF_ERR_UNSUPPORTED;
+  }
+  m->meshfile = file;
   int rc = open_h5(m.get(), file);
   if (rc != WF_OK) return rc;
   *out = m.release();
@@ -262,6 +270,7 @@ int wf_mesh_sizes(wf_mesh_file* m, int64_t* nverts, int64_t* ncells)
   WF_REQUIRE(m && nverts && ncells, "wf_mesh_sizes: null argument");
   std::vector<hsize_t> dt, dg;
   int rc;
+  if ((rc = open_h5(m, m->meshfile)) != WF_OK) return rc;   // the tag grids may live in another file
   if ((rc = dataset_dims(m, m->topo, &dt)) != WF_OK || (rc = dataset_dims(m, m->geom, &dg)) != WF_OK) return rc;
   if (dt.size() != 2 || dt[1] != 8) {
     wf::set_error("wf_mesh_sizes: topology must be [ncells][8] (hexahedra)");   // the operators are hexahedral
@@ -283,7 +292,7 @@ int wf_mesh_read(wf_mesh_file* m, double* h_xverts, int32_t* h_cells)
   int rc = wf_mesh_sizes(m, &nv, &nc);
   if (rc != WF_OK) return rc;
   std::vector<hsize_t> dg;
-  if ((rc = dataset_dims(m, m->geom, &dg)) != WF_OK) return rc;
+  if ((rc = dataset_dims(m, m->geom, &dg)) != WF_OK) return rc;   // wf_mesh_sizes has (re)opened the mesh file
   std::vector<double> g((size_t)nv * dg[1]);
   if ((rc = dataset_read(m, m->geom, h5()->NATIVE_DOUBLE, g.data())) != WF_OK) return rc;
   for (int64_t v = 0; v < nv; ++v)
@@ -328,22 +337,39 @@ int wf_mesh_tags_size(wf_mesh_file* m, const char* tags_name, int64_t* nfacets)
 int wf_mesh_read_tags(wf_mesh_file* m, const char* tags_name, int32_t* h_facet_verts, int32_t* h_values)
 {
   WF_REQUIRE(m && tags_name && h_facet_verts && h_values, "wf_mesh_read_tags: null argument");
-  int64_t nf;
-  int rc = wf_mesh_tags_size(m, tags_name, &nf);
+  int64_t nf, nv = 0, nc = 0;
+  int rc = wf_mesh_sizes(m, &nv, &nc);
   if (rc != WF_OK) return rc;
+  if ((rc = wf_mesh_tags_size(m, tags_name, &nf)) != WF_OK) return rc;
   size_t from, to;
   grid_block(m->xml, tags_name, &from, &to);
-  std::string file, topo, vals;
-  data_item(m->xml, from, to, "Topology", &file, &topo);
-  if (!data_item(m->xml, from, to, "Attribute", &file, &vals)) {
+  std::string file_t, file_v, topo, vals;
+  data_item(m->xml, from, to, "Topology", &file_t, &topo);
+  if (!data_item(m->xml, from, to, "Attribute", &file_v, &vals)) {
     wf::set_error("wf_mesh_read_tags: the tag grid needs an <Attribute> DataItem");
     return WF_ERR_INVALID;
   }
+  if ((rc = open_h5(m, file_t)) != WF_OK) return rc;
   std::vector<int64_t> t((size_t)nf * 4);
   if ((rc = dataset_read(m, topo, h5()->NATIVE_INT64, t.data())) != WF_OK) return rc;
   static const int kTensorFromXdmf[4] = {0, 1, 3, 2};
   for (int64_t f = 0; f < nf; ++f)
-    for (int v = 0; v < 4; ++v) h_facet_verts[f * 4 + v] = (int32_t)t[f * 4 + kTensorFromXdmf[v]];
+    for (int v = 0; v < 4; ++v) {
+      const int64_t id = t[f * 4 + kTensorFromXdmf[v]];
+      WF_REQUIRE(id >= 0 && id < nv, "wf_mesh_read_tags: facet vertex index out of range");
+      h_facet_verts[f * 4 + v] = (int32_t)id;
+    }
+  // the caller's h_values has nf entries (the size wf_mesh_tags_size reported from the tag TOPOLOGY): the
+  // Values dataset -- in the file ITS DataItem names -- must have exactly that many, as [nf] or [nf][1]
+  if ((rc = open_h5(m, file_v)) != WF_OK) return rc;
+  std::vector<hsize_t> dv;
+  if ((rc = dataset_dims(m, vals, &dv)) != WF_OK) return rc;
+  hsize_t nvals = 1;
+  for (hsize_t d : dv) nvals *= d;
+  if (dv.empty() || dv.size() > 2 || (dv.size() == 2 && dv[1] != 1) || nvals != (hsize_t)nf) {
+    wf::set_error("wf_mesh_read_tags: the Values dataset must hold one value per tagged facet ([nfacets] or [nfacets][1])");
+    return WF_ERR_INVALID;
+  }
   return dataset_read(m, vals, h5()->NATIVE_INT32, h_values);
 }
 

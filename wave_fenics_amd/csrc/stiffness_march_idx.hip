@@ -64,14 +64,16 @@ __device__ __forceinline__ void mass_column(const double* __restrict__ U, int sk
     for (int q = 0; q < n; ++q) {
       double s_ = 0.0;
 #pragma unroll
-      for (int k = 0; k < n; ++k) s_ += pm.v[q * n + k] * vy[k];
+      for (int k = 0; k < n; ++k) s_ += (P >= 5 ? sP[q * n + k] : pm.v[q * n + k]) * vy[k];   // P >= 5: see below
       w[q] = s_ * dj[q];
     }
 #pragma unroll
     for (int k = 0; k < n; ++k) {
       double s_ = 0.0;
 #pragma unroll
-      for (int q = 0; q < n; ++q) s_ += pm.v[q * n + k] * w[q];
+      // z-direction entries of phi: kernel-argument constants in SGPRs up to P4; from P5 on 2 n^2 SGPRs are
+      // more than a wave has (176 SGPR spills = v_readlane pairs at P6) -- broadcast reads of the LDS copy instead
+      for (int q = 0; q < n; ++q) s_ += (P >= 5 ? sP[q * n + k] : pm.v[q * n + k]) * w[q];
       B[k * n2 + ji] = s_;   // B1[k][qj][qi]
     }
   }

@@ -75,10 +75,39 @@ __global__ void k_div(int64_t n, const double* b, const double* m, double* out)
   for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (int64_t)gridDim.x * blockDim.x)
     out[g] = b[g] / m[g];
 }
+// The same with 16-byte accesses; the diagonal m and the result bypass the caches (non-temporal): inside the
+// RK4 loop / the bench step they are streamed once per pass, while b (= y of the stiffness apply) and the
+// apply's x are what the next stiffness apply touches again and should keep the Infinity Cache
+// (cfg2: 4 x 82 MB of vectors do not fit its 256 MB, x + y do).
+__global__ void k_div2(int64_t npairs, const double* __restrict__ b, const double* __restrict__ m, double* __restrict__ out)
+{
+  typedef double d2v __attribute__((ext_vector_type(2)));
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < npairs; g += (int64_t)gridDim.x * blockDim.x) {
+    const d2v bb = reinterpret_cast<const d2v*>(b)[g];
+    const d2v mm = __builtin_nontemporal_load(reinterpret_cast<const d2v*>(m) + g);
+    d2v r;
+    r.x = bb.x / mm.x;
+    r.y = bb.y / mm.y;
+    __builtin_nontemporal_store(r, reinterpret_cast<d2v*>(out) + g);
+  }
+}
 __global__ void k_mult_add(int64_t n, const double* __restrict__ m, const double* __restrict__ x, double* y)
 {
   for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (int64_t)gridDim.x * blockDim.x)
     y[g] += m[g] * x[g];
+}
+// y += m .* x with 16-byte accesses, the diagonal streamed past the caches
+__global__ void k_mult_add2(int64_t npairs, const double* __restrict__ m, const double* __restrict__ x, double* __restrict__ y)
+{
+  typedef double d2v __attribute__((ext_vector_type(2)));
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < npairs; g += (int64_t)gridDim.x * blockDim.x) {
+    const d2v mm = __builtin_nontemporal_load(reinterpret_cast<const d2v*>(m) + g);
+    const d2v xx = reinterpret_cast<const d2v*>(x)[g];
+    d2v yy = reinterpret_cast<d2v*>(y)[g];
+    yy.x += mm.x * xx.x;
+    yy.y += mm.y * xx.y;
+    reinterpret_cast<d2v*>(y)[g] = yy;
+  }
 }
 // common/cuda/la.hpp:87-103 inner_product: wave shuffle -> LDS -> one atomic per workgroup
 __global__ void k_dot(int64_t n, const double* __restrict__ x, const double* __restrict__ y,
@@ -252,14 +281,26 @@ int wf_scale(int64_t n, double alpha, double* d_x, void* stream)
 int wf_pointwise_div(int64_t n, const double* d_b, const double* d_m, double* d_out, void* stream)
 {
   if (n <= 0) return WF_OK;
-  hipLaunchKernelGGL(k_div, dim3(capped_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, n, d_b, d_m, d_out);
+  const bool vec = ((reinterpret_cast<uintptr_t>(d_b) | reinterpret_cast<uintptr_t>(d_m) | reinterpret_cast<uintptr_t>(d_out)) & 15) == 0
+                   && d_out != d_b && d_out != d_m;
+  const int64_t nv = vec ? n / 2 : 0;
+  if (nv) hipLaunchKernelGGL(k_div2, dim3(capped_grid(nv, 256)), dim3(256), 0, (hipStream_t)stream, nv, d_b, d_m, d_out);
+  if (n > 2 * nv)
+    hipLaunchKernelGGL(k_div, dim3(capped_grid(n - 2 * nv, 256)), dim3(256), 0, (hipStream_t)stream, n - 2 * nv, d_b + 2 * nv,
+                       d_m + 2 * nv, d_out + 2 * nv);
   WF_LAUNCH_CHECK();
   return WF_OK;
 }
 int wf_pointwise_mult_add(int64_t n, const double* d_m, const double* d_x, double* d_y, void* stream)
 {
   if (n <= 0) return WF_OK;
-  hipLaunchKernelGGL(k_mult_add, dim3(capped_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, n, d_m, d_x, d_y);
+  const bool vec = ((reinterpret_cast<uintptr_t>(d_m) | reinterpret_cast<uintptr_t>(d_x) | reinterpret_cast<uintptr_t>(d_y)) & 15) == 0
+                   && d_y != d_x && d_y != d_m;
+  const int64_t nv = vec ? n / 2 : 0;
+  if (nv) hipLaunchKernelGGL(k_mult_add2, dim3(capped_grid(nv, 256)), dim3(256), 0, (hipStream_t)stream, nv, d_m, d_x, d_y);
+  if (n > 2 * nv)
+    hipLaunchKernelGGL(k_mult_add, dim3(capped_grid(n - 2 * nv, 256)), dim3(256), 0, (hipStream_t)stream, n - 2 * nv, d_m + 2 * nv,
+                       d_x + 2 * nv, d_y + 2 * nv);
   WF_LAUNCH_CHECK();
   return WF_OK;
 }

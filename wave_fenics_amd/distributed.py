@@ -405,20 +405,25 @@ def overlapped_apply(op, updater: VectorUpdater, x, y):
     main.wait_stream(side)
 
 
-def owned_boundary(updater: VectorUpdater, V, tags, tag: int, device):
-    """The tagged boundary dof set of a domain-decomposed mesh reduced to OWNED dofs
-    with fully assembled facet masses: the rank-local collocated masses
-    (facet_lumped_mass) are accumulated to their owners once at setup
-    (scatter_rev), so that the boundary term b[i] += s m[i] v[i] is applied by the
-    owner alone and needs no ghost value of v -- the second forward update per
+def owned_boundary_set(updater: VectorUpdater, V, idx, m, device):
+    """A boundary dof set of a domain-decomposed mesh (indices, rank-local collocated facet masses)
+    reduced to OWNED dofs with fully assembled masses: the rank-local masses are accumulated to
+    their owners once at setup (scatter_rev), so that the boundary term b[i] += s m[i] v[i] is
+    applied by the owner alone and needs no ghost value of v -- the second forward update per
     stage of the reference (LinearGLL.hpp:167) disappears."""
     import torch
-    from .linear_gll import facet_lumped_mass
-    idx, m = facet_lumped_mass(V, tags, tag)
+    idx = np.asarray(idx)
     dense = torch.zeros(V.ndofs, dtype=torch.float64, device=device)
     if idx.size:
-        dense[torch.from_numpy(idx.astype(np.int64)).to(device)] = torch.from_numpy(m).to(device)
+        dense[torch.from_numpy(idx.astype(np.int64)).to(device)] = torch.from_numpy(np.ascontiguousarray(m, dtype=np.float64)).to(device)
     updater.scatter_rev(dense)
     h = dense.cpu().numpy()
     sel = np.nonzero((h != 0.0) & updater.part.owned_mask())[0].astype(np.int32)
     return sel, h[sel]
+
+
+def owned_boundary(updater: VectorUpdater, V, tags, tag: int, device):
+    """owned_boundary_set for the faces of a box partition carrying `tag`."""
+    from .linear_gll import facet_lumped_mass
+    idx, m = facet_lumped_mass(V, tags, tag)
+    return owned_boundary_set(updater, V, idx, m, device)

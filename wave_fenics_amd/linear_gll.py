@@ -119,7 +119,15 @@ class LinearGLLOpt:
                 i1, m1 = facet_lumped_mass(V, tags, 1)
                 i2, m2 = facet_lumped_mass(V, tags, 2)
         else:
+            # boundary = ((idx1, m1), (idx2, m2)): rank-local sets (any mix of owned and ghost dofs, rank-local
+            # facet masses).  On a partitioned mesh they go through the same accumulate-to-owner-and-filter
+            # step as the tag-derived sets: the loop below applies the boundary term to owned dofs only and
+            # never updates the ghosts of v (contract of owned_boundary_set).
             (i1, m1), (i2, m2) = boundary
+            if self.updater is not None:
+                from .distributed import owned_boundary_set
+                i1, m1 = owned_boundary_set(self.updater, V, i1, m1, self.device)
+                i2, m2 = owned_boundary_set(self.updater, V, i2, m2, self.device)
         td = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(self.device, dtype=dt)
         self.idx1, self.mG1 = td(i1, torch.int32), td(m1, torch.float64)
         self.idx2, self.mG2 = td(i2, torch.int32), td(m2, torch.float64)
@@ -129,6 +137,8 @@ class LinearGLLOpt:
         self._split = False
         if self.updater is not None:
             self._split = self.stiff_op.set_ghost_faces(*[bool(v) for v in self.updater.part.owned_lo])
+            if not self._split:   # arbitrary dofmap: split by the ghost positions the updater unpacks into
+                self._split = self.stiff_op.set_ghost_dofs(self.updater.h_ghost_pos)
         self.stiff_op(self.u_n, self.b)
         if self.updater is not None:
             self.updater.scatter_rev(self.b)
