@@ -1,10 +1,14 @@
 // planar3d -- the reference's CPU demo (demo/cpu_planar3d/main.cpp) on MI355X:
-// same physical constants, CFL rule and output lines; the mesh is a box generated
-// in-process (the reference reads ../mesh.xdmf, which is not in its repository)
-// with Gamma_1 = face x = 0 and Gamma_2 = every other face.
+// same physical constants, CFL rule and output lines.  The mesh is either read from an
+// XDMF + HDF5 file with its facet tags, as the reference does (main.cpp:39-45:
+// read_mesh(..., "planar3d"), read_meshtags(mesh, "planar3d_boundaries"); tag 1 = Gamma_1
+// source, tag 2 = Gamma_2 absorbing) -- any conforming hexahedral mesh, one rank -- or a box
+// generated in-process (the reference's own ../mesh.xdmf is not in its repository) with
+// Gamma_1 = face x = 0 and Gamma_2 = every other face.
 //
-//   planar3d [--size N] [--degree P] [--cfl C] [--steps S] [--length L] [--dump FILE]
-//            [--periodic xyz] [--reference-order]
+//   planar3d [--mesh FILE.xdmf [--grid NAME] [--tags NAME]]
+//            [--size N] [--degree P] [--cfl C] [--steps S] [--length L] [--dump FILE]
+//            [--periodic xyz] [--reference-order] [--markers]
 //
 // One process per GPU: with WORLD_SIZE > 1 in the environment (RANK, LOCAL_RANK,
 // MASTER_PORT as torchrun exports them) --size is the number of cells per edge PER
@@ -22,14 +26,16 @@
 #include <iostream>
 
 #include "wavehip_linear_gll.hpp"
+#include "wavehip_mesh.hpp"
 
 int main(int argc, char* argv[])
 {
   int size = 18, degreeOfBasis = 4, nsteps_override = -1;
   double CFL = 0.5, domainLength = 0.1;
   const char* dump = nullptr;
+  const char *mesh_file = nullptr, *grid_name = "planar3d", *tags_name = "planar3d_boundaries";
   std::array<bool, 3> periodic{false, false, false};
-  bool reference_order = false;
+  bool reference_order = false, markers = false;
   for (int i = 1; i < argc; ++i) {
     auto is = [&](const char* f) { return std::strcmp(argv[i], f) == 0 && i + 1 < argc; };
     if (is("--size")) size = std::atoi(argv[++i]);
@@ -38,13 +44,17 @@ int main(int argc, char* argv[])
     else if (is("--steps")) nsteps_override = std::atoi(argv[++i]);
     else if (is("--length")) domainLength = std::atof(argv[++i]);
     else if (is("--dump")) dump = argv[++i];
+    else if (is("--mesh")) mesh_file = argv[++i];
+    else if (is("--grid")) grid_name = argv[++i];
+    else if (is("--tags")) tags_name = argv[++i];
+    else if (std::strcmp(argv[i], "--markers") == 0) markers = true;
     else if (is("--periodic")) {
       for (const char* c = argv[++i]; *c; ++c)
         if (*c >= 'x' && *c <= 'z') periodic[*c - 'x'] = true;
     } else if (std::strcmp(argv[i], "--reference-order") == 0) reference_order = true;
     else {
-      std::cerr << "usage: planar3d [--size N] [--degree P] [--cfl C] [--steps S] [--length L] [--dump FILE]"
-                   " [--periodic xyz] [--reference-order]\n";
+      std::cerr << "usage: planar3d [--mesh FILE.xdmf [--grid NAME] [--tags NAME]] [--size N] [--degree P] [--cfl C]"
+                   " [--steps S] [--length L] [--dump FILE] [--periodic xyz] [--reference-order] [--markers]\n";
       return 2;
     }
   }
@@ -62,6 +72,42 @@ int main(int argc, char* argv[])
     double sourceFrequency = 0.5e6;
     double pressureAmplitude = 60000;
     double period = 1 / sourceFrequency;
+    if (markers) wavehip::check(wf_markers_enable(1));   // roctx ranges (nvtxMarkA in demo/gpu_scatter_mpi/main.cpp:101-121)
+
+    if (mesh_file) {
+      // ---- the reference's path: mesh + facet tags from a file (main.cpp:39-45) ----
+      if (exchange) throw std::runtime_error("--mesh runs on one rank");
+      auto [mesh, tags] = wavehip::read_mesh(mesh_file, grid_name, tags_name);
+      auto V = wavehip::create_functionspace(mesh, degreeOfBasis);
+      auto [timeStepSize, stepPerPeriod] = wavehip::cfl_time_step(mesh, degreeOfBasis, speedOfSound, sourceFrequency, CFL);
+      double startTime = 0.0;
+      double finalTime = domainLength / speedOfSound + 8.0 / sourceFrequency;
+      std::cout << "Number of step per period: " << stepPerPeriod << std::endl;
+      std::cout << "dt = " << timeStepSize << std::endl;
+      if (nsteps_override > 0) finalTime = nsteps_override * timeStepSize - 1e-13;
+      int nstep = (int)((finalTime - startTime) / timeStepSize + 1);
+      wavehip::LinearGLLOpt eqn(V.space(), wavehip::boundary_set(V, tags, 1), wavehip::boundary_set(V, tags, 2), degreeOfBasis,
+                                speedOfSound, sourceFrequency, pressureAmplitude);
+      std::cout << "Number of steps: " << nstep << std::endl;
+      std::cout << "Degrees of freedom: " << V.ndofs << std::endl;
+      eqn.init();
+      auto t0 = std::chrono::steady_clock::now();
+      int steps = reference_order ? eqn.rk4(startTime, finalTime, timeStepSize) : eqn.rk4_fused(startTime, finalTime, timeStepSize);
+      wavehip::check(wf_sync(nullptr));
+      double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      std::cout << "Steps taken: " << steps << std::endl;
+      std::cout << "Solve time: " << secs << std::endl;
+      if (dump) {
+        auto u = eqn.u_n->copy_to_host();
+        auto v = eqn.v_n->copy_to_host();
+        FILE* f = std::fopen(dump, "wb");
+        if (!f) throw std::runtime_error("cannot open dump file");
+        std::fwrite(u.data(), sizeof(double), u.size(), f);
+        std::fwrite(v.data(), sizeof(double), v.size(), f);
+        std::fclose(f);
+      }
+      return 0;
+    }
 
     const auto procs = wavehip::decompose3d(world);
     const double L = domainLength;

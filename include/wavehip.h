@@ -446,6 +446,16 @@ int wf_mesh_write(const char* xdmf_path, const char* grid_name, int64_t nverts, 
                   const int32_t* h_cells, const char* tags_name, int64_t nfacets, const int32_t* h_facet_verts,
                   const int32_t* h_values);
 
+/* ---- range markers (roctx) -----------------------------------------------------
+ * The nvtxMarkA / cudaProfilerStart bracketing of demo/gpu_scatter_mpi/main.cpp:89,101-121.
+ * wf_markers_enable(1) binds librocprofiler-sdk-roctx at run time; from then on wf_op_apply*,
+ * wf_updater_*, wf_rk4_stage and wf_cg push / pop a named range on the calling host thread
+ * (rocprofv3 --marker-trace).  Off by default; host code can add its own ranges. */
+int wf_markers_enable(int on);
+int wf_marker_push(const char* name);
+int wf_marker_pop(void);
+int wf_marker_mark(const char* name);
+
 /* ---- 8f: what DOLFINx derives from the mesh for the CPU demo (host only) ------------------
  * demo/cpu_planar3d/main.cpp:39-66, common/LinearGLL.hpp:113-115.  Cells and facets in the
  * engine's tensor vertex order (wf_mesh_read / wf_mesh_read_tags deliver it); cells may have ANY

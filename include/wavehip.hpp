@@ -129,7 +129,7 @@ public:
   OpBase() = default;
   OpBase(const OpBase&) = delete;
   OpBase& operator=(const OpBase&) = delete;
-  ~OpBase() { wf_op_destroy(_op); }
+  virtual ~OpBase() { wf_op_destroy(_op); }
   std::size_t num_quads() const { return info().num_quads; }
   std::size_t num_cells() const { return info().num_cells; }
   std::size_t num_dofs() const { return info().num_dofs_cell; }

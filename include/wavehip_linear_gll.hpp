@@ -2,8 +2,10 @@
 // class LinearGLLOpt with the reference's member names and call sequence
 // (common/LinearGLL.hpp:37-288), every vector on the device, every operation a
 // libwavehip call.  The mesh/meshtags constructor arguments of the reference are
-// replaced by a BoxSpace plus the facet tag map (tag 1 = Gamma_1 source,
-// tag 2 = Gamma_2 absorbing); the FFCx form L (demo/cpu_planar3d/forms.ufl:19-24)
+// replaced by either a BoxSpace plus the facet tag map (tag 1 = Gamma_1 source,
+// tag 2 = Gamma_2 absorbing), or -- the mesh-FILE path of demo/cpu_planar3d/main.cpp:39-45 --
+// a general Space plus the two tagged boundary dof sets (wavehip_mesh.hpp: read_mesh,
+// create_functionspace, boundary_set); the FFCx form L (demo/cpu_planar3d/forms.ufl:19-24)
 // is applied in its diagonal GLL form by wf_boundary_apply.
 //
 // Domain-decomposed runs pass a VectorUpdater (and the BoxPartition it was built
@@ -45,7 +47,7 @@ protected:
   std::unique_ptr<array<double>> m, b;
   std::unique_ptr<array<std::int32_t>> idx1, idx2;
   std::unique_ptr<array<double>> mG1, mG2;
-  std::unique_ptr<BoxStiffnessOperator<double>> stiff_op;
+  std::unique_ptr<detail::OpBase> stiff_op;
   VectorUpdater<double>* updater_ = nullptr;   // nullptr on one rank
   bool split_ = false;                         // interior / interface overlap available
 
@@ -75,16 +77,8 @@ protected:
     if (updater_) updater_->update_rev(b->data());
   }
 
-public:
-  const BoxSpace& V;
-  std::unique_ptr<array<double>> u_n, v_n;
-
-  LinearGLLOpt(const BoxSpace& V_, const std::map<int, int>& facet_tags, int degreeOfBasis, double speedOfSound,
-               double sourceFrequency, double pressureAmplitude, VectorUpdater<double>* updater = nullptr,
-               const BoxPartition* part = nullptr)
-      : updater_(updater), V(V_)
+  void set_parameters(int degreeOfBasis, double speedOfSound, double sourceFrequency, double pressureAmplitude)
   {
-    if (updater && !part) throw std::runtime_error("LinearGLLOpt: a VectorUpdater needs its BoxPartition");
     k_ = degreeOfBasis;
     c0_ = speedOfSound;
     freq0_ = sourceFrequency;
@@ -92,7 +86,62 @@ public:
     w0_ = 2.0 * M_PI * freq0_;
     T_ = 1.0 / freq0_;
     alpha_ = 4.0;
-    N_ = V.ndofs();
+  }
+  template <class C>
+  static auto upload(const C& h)
+  {
+    auto a = std::make_unique<array<typename C::value_type>>(h.size());
+    a->set(h);
+    return a;
+  }
+
+public:
+  const BoxSpace* V = nullptr;   // the box constructor's space (nullptr for the general-Space constructor)
+  std::unique_ptr<array<double>> u_n, v_n;
+
+  using BoundarySet = std::pair<std::vector<std::int32_t>, std::vector<double>>;
+
+  /// The mesh-file path (demo/cpu_planar3d/main.cpp:39-45, common/LinearGLL.hpp:53-128): any conforming
+  /// hexahedral space plus the dof sets of Gamma_1 (source) and Gamma_2 (absorbing) with their collocated
+  /// facet masses (wavehip_mesh.hpp boundary_set).  One rank.
+  LinearGLLOpt(const Space& S, const BoundarySet& gamma1, const BoundarySet& gamma2, int degreeOfBasis, double speedOfSound,
+               double sourceFrequency, double pressureAmplitude)
+  {
+    set_parameters(degreeOfBasis, speedOfSound, sourceFrequency, pressureAmplitude);
+    N_ = S.ndofs;
+    auto zeros = [&]() {
+      auto a = std::make_unique<array<double>>((std::size_t)N_);
+      check(wf_fill(N_, 0.0, a->data(), nullptr));
+      return a;
+    };
+    u_n = zeros();
+    v_n = zeros();
+    m = zeros();
+    b = zeros();
+    {   // LinearGLL.hpp:102-110: m = M * 1
+      array<double> ones((std::size_t)N_);
+      check(wf_fill(N_, 1.0, ones.data(), nullptr));
+      MassOperatorLumped<double> mass(S, k_);
+      mass.apply(ones.data(), m->data());
+      check(wf_sync(nullptr));
+    }
+    idx1 = upload(gamma1.first);
+    mG1 = upload(gamma1.second);
+    idx2 = upload(gamma2.first);
+    mG2 = upload(gamma2.second);
+    std::map<std::string, double> params{{"c0", c0_}};
+    stiff_op = std::make_unique<StiffnessOperator<double>>(S, k_, params);   // LinearGLL.hpp:120-127
+    stiffness(u_n->data());
+  }
+
+  LinearGLLOpt(const BoxSpace& V_, const std::map<int, int>& facet_tags, int degreeOfBasis, double speedOfSound,
+               double sourceFrequency, double pressureAmplitude, VectorUpdater<double>* updater = nullptr,
+               const BoxPartition* part = nullptr)
+      : updater_(updater), V(&V_)
+  {
+    if (updater && !part) throw std::runtime_error("LinearGLLOpt: a VectorUpdater needs its BoxPartition");
+    set_parameters(degreeOfBasis, speedOfSound, sourceFrequency, pressureAmplitude);
+    N_ = V->ndofs();
     auto zeros = [&]() {
       auto a = std::make_unique<array<double>>((std::size_t)N_);
       check(wf_fill(N_, 0.0, a->data(), nullptr));
@@ -107,7 +156,7 @@ public:
       array<double> ones((std::size_t)N_);
       check(wf_fill(N_, 1.0, ones.data(), nullptr));
       wf_op* mass = nullptr;
-      check(wf_op_create_box(WF_OP_MASS_LUMPED, k_, V.mesh->n[0], V.mesh->n[1], V.mesh->n[2], V.mesh->x.data(), 0.0,
+      check(wf_op_create_box(WF_OP_MASS_LUMPED, k_, V->mesh->n[0], V->mesh->n[1], V->mesh->n[2], V->mesh->x.data(), 0.0,
                              WF_FLAG_NONE, &mass));
       check(wf_op_apply(mass, ones.data(), m->data(), nullptr));
       if (updater_) {
@@ -129,7 +178,7 @@ public:
       return a;
     };
     auto facet = [&](int tag) {
-      auto f = facet_lumped_mass(V, facet_tags, tag);
+      auto f = facet_lumped_mass(*V, facet_tags, tag);
       if (!updater_) return f;
       // accumulate the rank-local facet masses to their owners, keep owned dofs only
       std::vector<double> dense((std::size_t)N_, 0.0);
@@ -154,8 +203,8 @@ public:
     idx2 = up_i(f2.first);
     mG2 = up_d(f2.second);
     // LinearGLL.hpp:120-127
-    stiff_op = std::make_unique<BoxStiffnessOperator<double>>(k_, V.mesh->n[0], V.mesh->n[1], V.mesh->n[2],
-                                                              V.mesh->x.data(), c0_);
+    stiff_op = std::make_unique<BoxStiffnessOperator<double>>(k_, V->mesh->n[0], V->mesh->n[1], V->mesh->n[2],
+                                                              V->mesh->x.data(), c0_);
     if (updater_) {
       const int rc = wf_op_set_ghost_faces(stiff_op->handle(), part->owned_lo[0], part->owned_lo[1], part->owned_lo[2]);
       if (rc != WF_OK && rc != WF_ERR_UNSUPPORTED) check(rc);

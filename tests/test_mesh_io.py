@@ -150,6 +150,44 @@ def test_rk4_from_mesh_file(oracle, tmp_path):
     assert np.abs(u[ib] - ref.u_n[ia]).max() <= 1e-9 * np.abs(ref.u_n).max()
     assert np.abs(v[ib] - ref.v_n[ia]).max() <= 1e-9 * np.abs(ref.v_n).max()
 
+@pytest.mark.gpu
+def test_rk4_from_mesh_file_cxx(oracle, tmp_path):
+    """The same flow through the C++ host code (include/wavehip_mesh.hpp + the Space constructor of
+    wavehip::LinearGLLOpt, examples/planar3d --mesh FILE): mesh and facet tags read from the file in
+    C++, function space / boundary sets / CFL step derived in C++, fused and reference-order RK4,
+    with roctx range markers on -- against the oracle on the original box
+    (demo/cpu_planar3d/main.cpp:39-66)."""
+    import subprocess
+    from wave_fenics_amd import mesh_io
+    p, n, hi = 3, (4, 3, 3), (0.01, 0.0075, 0.0075)
+    om, mesh, tags = shuffled_box(oracle, n, p, hi, 0.15)
+    path = str(tmp_path / "mesh.xdmf")
+    mesh_io.write_mesh(path, "planar3d", mesh, "planar3d_boundaries", tags)
+    out = str(tmp_path / "bin")
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "examples"), f"OUT={out}", f"{out}/planar3d"])
+    dt, spp = oracle.cfl_time_step(om, p, 1500.0, 0.5e6, CFL=0.25)
+    ref = oracle.LinearGLLOpt(om, p, 1500.0, 0.5e6, 6e4)
+    ref.init()
+    ref.rk4(0.0, 20 * dt - 1e-13, dt)
+    V = mesh_io.create_functionspace(mesh_io.read_mesh(path, "planar3d"), p)     # the numbering the C++ side derives too
+    X = oracle.dof_coordinates(om)
+    e = np.linalg.norm(om.x[om.geom_dofmap[:, 1]] - om.x[om.geom_dofmap[:, 0]], axis=1).min()
+    qa = np.round(X / (1e-9 * e)).astype(np.int64)
+    qb = np.round(V.dof_coordinates / (1e-9 * e)).astype(np.int64)
+    ia, ib = np.lexsort(qa.T[::-1]), np.lexsort(qb.T[::-1])
+    assert np.array_equal(qa[ia], qb[ib])
+    for extra in (["--markers"], ["--reference-order"]):
+        dump = str(tmp_path / "uv.bin")
+        r = subprocess.run([os.path.join(out, "planar3d"), "--mesh", path, "--degree", str(p), "--cfl", "0.25", "--steps", "20",
+                            "--dump", dump] + extra, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "Steps taken: 20" in r.stdout and f"Degrees of freedom: {om.ndofs}" in r.stdout
+        assert f"Number of step per period: {spp}" in r.stdout
+        uv = np.fromfile(dump, dtype=np.float64)
+        assert uv.size == 2 * om.ndofs
+        u, v = uv[: om.ndofs], uv[om.ndofs:]
+        assert np.abs(u[ib] - ref.u_n[ia]).max() <= 1e-9 * np.abs(ref.u_n).max()
+        assert np.abs(v[ib] - ref.v_n[ia]).max() <= 1e-9 * np.abs(ref.v_n).max()
 
 
 def test_tag_reader_checks_extents_and_ranges(tmp_path):

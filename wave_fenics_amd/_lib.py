@@ -160,6 +160,10 @@ SIGNATURES = {
     "wf_mesh_read_tags": (c_int, [c_void_p, c_char_p, _ip, _ip]),
     "wf_mesh_close": (c_int, [c_void_p]),
     "wf_mesh_write": (c_int, [c_char_p, c_char_p, c_int64, _dp, c_int64, _ip, c_char_p, c_int64, _ip, _ip]),
+    "wf_markers_enable": (c_int, [c_int]),
+    "wf_marker_push": (c_int, [c_char_p]),
+    "wf_marker_pop": (c_int, []),
+    "wf_marker_mark": (c_int, [c_char_p]),
     "wf_fs_build": (c_int, [c_int, c_int64, _dp, c_int64, _ip, POINTER(c_int64), _ip, _dp, c_int64]),
     "wf_fs_locate_facets": (c_int, [c_int64, _ip, c_int64, _ip, _ip, _ip, _ip]),
     "wf_fs_facet_mass": (c_int, [c_int, c_int64, _dp, c_int64, _ip, _ip, c_int64, _ip, _ip, _ip, POINTER(c_int64), _ip, _dp]),

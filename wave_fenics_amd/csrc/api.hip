@@ -986,6 +986,7 @@ static int launch_box_march(const wf_op* op, int lz0, const double* d_x, double*
 int wf_op_apply(wf_op* op, const double* d_x, double* d_y, void* stream)
 {
   WF_REQUIRE(op && d_x && d_y, "wf_op_apply: null argument");
+  MarkerScope mk("wf_op_apply");
   hipStream_t s = (hipStream_t)stream;
   if (op->dense) return launch_stiffness_dense(op->dense, op->coeff, op->dense_clamp, d_x, d_y, s);
   if (op->structured) {
@@ -1152,6 +1153,9 @@ int wf_op_apply_part(wf_op* op, const double* d_x, double* d_y, int part, void* 
   }
   const int k = part - 1;   // WF_PART_INTERIOR, _INTERFACE, _INTERIOR_A, _INTERIOR_B
   if (op->nitems[k] == 0) return WF_OK;
+  static const char* kPartName[4] = {"wf_op_apply_part interior", "wf_op_apply_part interface", "wf_op_apply_part interior A",
+                                     "wf_op_apply_part interior B"};
+  MarkerScope mk(kPartName[k]);
   if (op->structured) return launch_box_march(op, op->lz0_split, d_x, d_y, op->d_items[k], op->nitems[k], (hipStream_t)stream);
   return launch_stiffness_march_idx(op->P, op->plan, op->d_G6blk, op->d_D, op->dm, op->coeff, d_x, d_y, op->d_items[k],
                                     op->nitems[k], (hipStream_t)stream);

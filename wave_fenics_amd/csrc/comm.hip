@@ -198,12 +198,14 @@ int wait_exchange(wf_updater* u, hipStream_t user, bool inl)
 // VectorUpdater.hpp:106-131: pack the owned values the neighbours hold as ghosts, post the exchange
 int fwd_begin(wf_updater* u, const double* d_x, hipStream_t s, bool inl)
 {
+  wf::MarkerScope mk("update_fwd_begin");
   return begin(u, u->d_indices, u->nsend, d_x, u->d_send_buffer, u->send_off, u->send_nb, u->d_recv_buffer, u->recv_off,
                u->recv_nb, s, inl);
 }
 // VectorUpdater.hpp:133-143: wait, copy into the ghost entries
 int fwd_end(wf_updater* u, double* d_x, hipStream_t s, bool inl)
 {
+  wf::MarkerScope mk("update_fwd_end");
   int rc = wait_exchange(u, s, inl);
   if (rc != WF_OK) return rc;
   return wf_scatter_set(u->nrecv, u->d_ghost_pos, u->d_recv_buffer, d_x, s);
@@ -211,12 +213,14 @@ int fwd_end(wf_updater* u, double* d_x, hipStream_t s, bool inl)
 // VectorUpdater.hpp:157-189: the buffers swap roles: pack the ghost entries, send them to their owners
 int rev_begin(wf_updater* u, const double* d_x, hipStream_t s, bool inl)
 {
+  wf::MarkerScope mk("update_rev_begin");
   return begin(u, u->d_ghost_pos, u->nrecv, d_x, u->d_recv_buffer, u->recv_off, u->recv_nb, u->d_send_buffer, u->send_off,
                u->send_nb, s, inl);
 }
 // VectorUpdater.hpp:191-199: wait, accumulate into the owned entries (atomic add, scatter.cu:43)
 int rev_end(wf_updater* u, double* d_x, hipStream_t s, bool inl)
 {
+  wf::MarkerScope mk("update_rev_end");
   int rc = wait_exchange(u, s, inl);
   if (rc != WF_OK) return rc;
   return wf_scatter_add(u->nsend, u->d_indices, u->d_send_buffer, d_x, s);
@@ -479,6 +483,7 @@ int wf_updater_destroy(wf_updater* u)
 int wf_op_apply_overlapped(wf_op* op, wf_updater* u, double* d_x, double* d_y, void* stream)
 {
   WF_REQUIRE(op && u && d_x && d_y, "wf_op_apply_overlapped: null argument");
+  wf::MarkerScope mk("wf_op_apply_overlapped");
   hipStream_t main = (hipStream_t)stream, side = u->side_stream;
   int rc;
   // Default: the halo chain (pack, RCCL, unpack, interface cells, and the same in reverse) runs on

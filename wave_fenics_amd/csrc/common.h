@@ -27,6 +27,15 @@ constexpr int kMaxN = kMaxDegree + 1;
 
 void set_error(const std::string& msg);
 
+// roctx range markers (markers.cpp); no-ops unless wf_markers_enable(1)
+bool markers_on();
+void marker_push(const char* name);
+void marker_pop();
+struct MarkerScope {
+  explicit MarkerScope(const char* name) { marker_push(name); }
+  ~MarkerScope() { marker_pop(); }
+};
+
 #define WF_HIP_CHECK(expr)                                                          \
   do {                                                                              \
     hipError_t _e = (expr);                                                         \

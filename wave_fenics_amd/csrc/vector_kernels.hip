@@ -319,6 +319,7 @@ int wf_rk4_stage(int64_t n, double bdt, double adt_next, int has_next, double* d
   if (n <= 0) return WF_OK;
   WF_REQUIRE(d_b && d_m && d_vn && d_u_read && d_v_read && d_u && d_v, "wf_rk4_stage: null vector");
   WF_REQUIRE(!has_next || (d_u0 && d_v0 && d_un && d_vn_next), "wf_rk4_stage: next-stage vectors missing");
+  MarkerScope mk("wf_rk4_stage");
   WF_REQUIRE(!has_next || d_vn_next != d_vn, "wf_rk4_stage: vn_next must not alias vn");
   hipStream_t st = (hipStream_t)stream;
   auto aligned = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
