@@ -328,6 +328,23 @@ int wf_boundary_apply(int32_t n1, const int32_t* d_idx1, const double* d_m1, dou
                       int32_t n2, const int32_t* d_idx2, const double* d_m2, double s2,
                       const double* d_v, double* d_b, void* stream);
 
+/* The boundary term folded into the fused stage: a plan of the two boundary dof sets (host arrays, as
+ * wf_boundary_apply takes them on the device) -- a bitmap over the n dofs, a running count per 64 dofs and
+ * the facet masses of the union set in dof order.  wf_rk4_stage_bc is wf_rk4_stage that, instead of zeroing
+ * b, leaves the NEXT right-hand side's boundary term in it:
+ *   b[i] = s1_next m1[i] + s2 m2[i] v'[i],  v' = vn_next (has_next) or the updated v (last stage),
+ * so the separate wf_boundary_apply launch per stage disappears (LinearGLL.hpp:173-175; the stiffness apply
+ * then accumulates onto it).  wf_boundary_apply_plan is the plain launch (first right-hand side of a run). */
+typedef struct wf_boundary wf_boundary;
+int wf_boundary_create(int64_t n, int32_t n1, const int32_t* h_idx1, const double* h_m1, int32_t n2, const int32_t* h_idx2,
+                       const double* h_m2, wf_boundary** out);
+int wf_boundary_destroy(wf_boundary* bc);
+int wf_boundary_apply_plan(const wf_boundary* bc, double s1, double s2, const double* d_v, double* d_b, void* stream);
+int wf_rk4_stage_bc(int64_t n, double bdt, double adt_next, int has_next, double* d_b, const double* d_m,
+                    const double* d_vn, const double* d_u_read, const double* d_v_read, double* d_u, double* d_v,
+                    const double* d_u0, const double* d_v0, double* d_un, double* d_vn_next, const wf_boundary* bc,
+                    double s1_next, double s2, void* stream);
+
 /* ---- a14: ghost exchange over RCCL ----------------------------------------
  * demo/gpu_scatter_mpi/VectorUpdater.hpp:21-230 (GPU pack + CUDA-aware MPI per
  * IndexMap neighbour) and la::Vector::scatter_fwd / scatter_rev(add) of

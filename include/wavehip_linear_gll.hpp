@@ -48,6 +48,7 @@ protected:
   std::unique_ptr<array<std::int32_t>> idx1, idx2;
   std::unique_ptr<array<double>> mG1, mG2;
   std::unique_ptr<detail::OpBase> stiff_op;
+  wf_boundary* bc_ = nullptr;                  // boundary plan of the fused loop (created on first use)
   VectorUpdater<double>* updater_ = nullptr;   // nullptr on one rank
   bool split_ = false;                         // interior / interface overlap available
 
@@ -213,6 +214,10 @@ public:
     stiffness(u_n->data());
   }
 
+  ~LinearGLLOpt() { wf_boundary_destroy(bc_); }
+  LinearGLLOpt(const LinearGLLOpt&) = delete;
+  LinearGLLOpt& operator=(const LinearGLLOpt&) = delete;
+
   /// Set the initial values of u and v (LinearGLL.hpp:131-134)
   void init()
   {
@@ -292,21 +297,30 @@ public:
     const double a_runge[4] = {0.0, 0.5, 0.5, 1.0};
     const double b_runge[4] = {1.0 / 6.0, 1.0 / 3.0, 1.0 / 3.0, 1.0 / 6.0};
     const double c_runge[4] = {0.0, 0.5, 0.5, 1.0};
+    // The boundary term of each right-hand side is left in b by the stage kernel in front of it
+    // (wf_rk4_stage_bc), the first one by a plain launch: a stage is two launches, stiffness + vector algebra.
+    if (!bc_) {
+      const auto i1 = idx1->copy_to_host(), i2 = idx2->copy_to_host();
+      const auto a1 = mG1->copy_to_host(), a2 = mG2->copy_to_host();
+      check(wf_boundary_create(N_, (std::int32_t)i1.size(), i1.data(), a1.data(), (std::int32_t)i2.size(), i2.data(), a2.data(), &bc_));
+    }
     check(wf_fill(N_, 0.0, b->data(), nullptr));
+    check(wf_boundary_apply_plan(bc_, c0_ * c0_ * source(t), -c0_, v0->data(), b->data(), nullptr));
     while (t < tf) {
       dt = std::min(dt, tf - t);
       double* x_u = u0->data();           // stage 0 reads u0 / v0 directly (a_0 = 0)
       double* x_v = v0->data();
       double* vn_next = vn_a->data();
       for (int i = 0; i < 4; ++i) {
-        const double g = source(t + c_runge[i] * dt);
         stiffness(x_u);
-        boundary(g, x_v);
         const double* ur = i == 0 ? u0->data() : u_->data();
         const double* vr = i == 0 ? v0->data() : v_->data();
         const int has_next = i < 3;
-        check(wf_rk4_stage(N_, dt * b_runge[i], has_next ? dt * a_runge[i + 1] : 0.0, has_next, b->data(), m->data(), x_v,
-                           ur, vr, u_->data(), v_->data(), u0->data(), v0->data(), un->data(), vn_next, nullptr));
+        // time of the next right-hand side: the next stage, or stage 0 of the next step
+        const double g_next = source(has_next ? t + c_runge[i + 1] * dt : t + dt);
+        check(wf_rk4_stage_bc(N_, dt * b_runge[i], has_next ? dt * a_runge[i + 1] : 0.0, has_next, b->data(), m->data(), x_v,
+                              ur, vr, u_->data(), v_->data(), u0->data(), v0->data(), un->data(), vn_next, bc_,
+                              c0_ * c0_ * g_next, -c0_, nullptr));
         if (has_next) {
           x_u = un->data();
           x_v = vn_next;

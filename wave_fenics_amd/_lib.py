@@ -135,6 +135,10 @@ SIGNATURES = {
     "wf_pointwise_mult_add": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "wf_dot": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "wf_rk4_stage": (c_int, [c_int64, c_double, c_double, c_int] + [c_void_p] * 12),
+    "wf_boundary_create": (c_int, [c_int64, c_int32, _ip, _dp, c_int32, _ip, _dp, POINTER(c_void_p)]),
+    "wf_boundary_destroy": (c_int, [c_void_p]),
+    "wf_boundary_apply_plan": (c_int, [c_void_p, c_double, c_double, c_void_p, c_void_p, c_void_p]),
+    "wf_rk4_stage_bc": (c_int, [c_int64, c_double, c_double, c_int] + [c_void_p] * 11 + [c_void_p, c_double, c_double, c_void_p]),
     "wf_comm_unique_id": (c_int, [c_char_p]),
     "wf_comm_create": (c_int, [c_char_p, c_int, c_int, POINTER(c_void_p)]),
     "wf_comm_rendezvous_file": (c_int, [c_char_p, c_int, c_double, c_char_p]),

@@ -3,6 +3,9 @@
 // a grid-stride loop capped at 256 CUs x 8 workgroups, 16-byte accesses where
 // the operands allow it.
 #include <cstdlib>
+#include <memory>
+#include <type_traits>
+#include <vector>
 #include <type_traits>
 
 #include "common.h"
@@ -152,63 +155,134 @@ __global__ void k_boundary(int32_t n1, const int32_t* __restrict__ idx1, const d
 // 208 B/dof of the reference's separate copy/axpy/fill/transform passes.
 // u_read/v_read may alias u_/v_ (stages 1..3) or be u0/v0 (stage 0).
 // VEC = 2: 16-byte accesses (all pointers 16-byte aligned, n counted in pairs).
-template <int VEC, bool HAS_NEXT, bool NT = false>
-__global__ void __launch_bounds__(256)
-k_rk4_stage(int64_t n, double bdt, double adt_next, double* b, const double* m, const double* vn,
-            const double* u_read, const double* v_read, double* u_, double* v_, const double* u0,
-            const double* v0, double* un, double* vn_next)
+// BC: instead of zeroing b for the next stiffness apply, leave the NEXT right-hand side's diagonal boundary
+// term in it (LinearGLL.hpp:175, forms.ufl:19-24): b[i] = s1 c1[r] + s2 c2[r] v'[i] for the dofs of the
+// boundary sets, v' = the v argument of the next f1 (vn_next, or the updated solution after the last stage).
+// The sets are a bitmap over the dofs (one 64-bit word per 64 dofs, L2-resident), a running count per word and
+// the two coefficient arrays over the union set in dof order: 0.2 B/dof read instead of a fifth launch per stage.
+struct BoundaryPlanDev {
+  const unsigned long long* mask = nullptr;   // [ceil(n / 64)]
+  const uint32_t* prefix = nullptr;           // [ceil(n / 64)] boundary dofs in front of the word
+  const double* c1 = nullptr;                 // [nb] facet mass of Gamma_1 (0 for dofs only in Gamma_2)
+  const double* c2 = nullptr;                 // [nb] facet mass of Gamma_2
+  double s1 = 0.0, s2 = 0.0;
+};
+
+struct StageArgs {
+  double bdt, adt_next;
+  double* b;
+  const double* m;
+  const double* vn;
+  const double* u_read;
+  const double* v_read;
+  double* u_;
+  double* v_;
+  const double* u0;
+  const double* v0;
+  double* un;
+  double* vn_next;
+  BoundaryPlanDev bc;
+};
+
+// entry g of the stage (VEC doubles wide) of arrays that start at dof `off`
+template <int VEC, bool HAS_NEXT, bool NT, bool BC>
+__device__ __forceinline__ void stage_entry(const StageArgs& a, int64_t g, int64_t off)
 {
   using V = typename std::conditional<VEC == 2, double2, double>::type;
   typedef double d2v __attribute__((ext_vector_type(2)));
   // NT: everything except the two vectors the next stiffness apply touches (un, b) bypasses the caches
-  auto ld = [](const double* p, int64_t g) -> V {
+  auto ld = [off](const double* p, int64_t g) -> V {
     if constexpr (NT && VEC == 2) {
-      const d2v v = __builtin_nontemporal_load(reinterpret_cast<const d2v*>(p) + g);
+      const d2v v = __builtin_nontemporal_load(reinterpret_cast<const d2v*>(p + off) + g);
       return make_double2(v.x, v.y);
     } else
-      return reinterpret_cast<const V*>(p)[g];
+      return reinterpret_cast<const V*>(p + off)[g];
   };
-  auto st = [](double* p, int64_t g, V v) { reinterpret_cast<V*>(p)[g] = v; };
-  auto stnt = [](double* p, int64_t g, V v) {
+  auto st = [off](double* p, int64_t g, V v) { reinterpret_cast<V*>(p + off)[g] = v; };
+  auto stnt = [off](double* p, int64_t g, V v) {
     if constexpr (NT && VEC == 2) {
       d2v w;
       w.x = v.x;
       w.y = v.y;
-      __builtin_nontemporal_store(w, reinterpret_cast<d2v*>(p) + g);
+      __builtin_nontemporal_store(w, reinterpret_cast<d2v*>(p + off) + g);
     } else
-      reinterpret_cast<V*>(p)[g] = v;
+      reinterpret_cast<V*>(p + off)[g] = v;
   };
-  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (int64_t)gridDim.x * blockDim.x) {
-    const V bb = ld(b, g), mm = ld(m, g), ku = ld(vn, g), ur = ld(u_read, g), vr = ld(v_read, g);
-    V kv, uo, vo, zero;
-    if constexpr (VEC == 2) {
-      kv = make_double2(bb.x / mm.x, bb.y / mm.y);
-      uo = make_double2(ku.x * bdt + ur.x, ku.y * bdt + ur.y);
-      vo = make_double2(kv.x * bdt + vr.x, kv.y * bdt + vr.y);
-      zero = make_double2(0.0, 0.0);
-    } else {
-      kv = bb / mm;
-      uo = ku * bdt + ur;
-      vo = kv * bdt + vr;
-      zero = 0.0;
-    }
-    if constexpr (HAS_NEXT) {
-      const V a0 = ld(u0, g), c0 = ld(v0, g);
-      V un_, vn_;
-      if constexpr (VEC == 2) {
-        un_ = make_double2(ku.x * adt_next + a0.x, ku.y * adt_next + a0.y);
-        vn_ = make_double2(kv.x * adt_next + c0.x, kv.y * adt_next + c0.y);
-      } else {
-        un_ = ku * adt_next + a0;
-        vn_ = kv * adt_next + c0;
-      }
-      st(un, g, un_);
-      stnt(vn_next, g, vn_);
-    }
-    stnt(u_, g, uo);
-    stnt(v_, g, vo);
-    st(b, g, zero);
+  const double bdt = a.bdt, adt_next = a.adt_next;
+  const V bb = ld(a.b, g), mm = ld(a.m, g), ku = ld(a.vn, g), ur = ld(a.u_read, g), vr = ld(a.v_read, g);
+  V kv, uo, vo, zero;
+  if constexpr (VEC == 2) {
+    kv = make_double2(bb.x / mm.x, bb.y / mm.y);
+    uo = make_double2(ku.x * bdt + ur.x, ku.y * bdt + ur.y);
+    vo = make_double2(kv.x * bdt + vr.x, kv.y * bdt + vr.y);
+    zero = make_double2(0.0, 0.0);
+  } else {
+    kv = bb / mm;
+    uo = ku * bdt + ur;
+    vo = kv * bdt + vr;
+    zero = 0.0;
   }
+  V vnext = vo;   // the v the next right-hand side sees
+  if constexpr (HAS_NEXT) {
+    const V a0 = ld(a.u0, g), c0 = ld(a.v0, g);
+    V un_, vn_;
+    if constexpr (VEC == 2) {
+      un_ = make_double2(ku.x * adt_next + a0.x, ku.y * adt_next + a0.y);
+      vn_ = make_double2(kv.x * adt_next + c0.x, kv.y * adt_next + c0.y);
+    } else {
+      un_ = ku * adt_next + a0;
+      vn_ = kv * adt_next + c0;
+    }
+    st(a.un, g, un_);
+    stnt(a.vn_next, g, vn_);
+    vnext = vn_;
+  }
+  stnt(a.u_, g, uo);
+  stnt(a.v_, g, vo);
+  if constexpr (BC) {
+    const BoundaryPlanDev& bc = a.bc;
+    const int64_t d0 = off + (int64_t)VEC * g;          // first dof of this entry
+    unsigned long long word;
+    bool any = true;
+    if constexpr (VEC == 2) {
+      // a wave covers 128 consecutive dofs = two mask words (off is 0 and g a multiple of 64 in lane 0): fetch
+      // them with scalar loads and skip the whole block when the wave holds no boundary dof (97 % of the waves)
+      const int64_t w0 = __builtin_amdgcn_readfirstlane((int)(d0 >> 6));
+      const unsigned long long wa = bc.mask[w0], wb = bc.mask[w0 + 1];   // mask has one spare word at the end
+      any = (wa | wb) != 0ull;
+      word = (d0 >> 6) == w0 ? wa : wb;
+    } else {
+      word = bc.mask[d0 >> 6];
+    }
+    if (any) {
+      const unsigned bits = (unsigned)(word >> (d0 & 63)) & (VEC == 2 ? 3u : 1u);   // VEC == 2: d0 is even, both dofs in one word
+      if (bits) {
+        const unsigned long long below = word & ((1ull << (d0 & 63)) - 1ull);
+        int64_t r = (int64_t)bc.prefix[d0 >> 6] + __popcll(below);
+        if constexpr (VEC == 2) {
+          if (bits & 1u) {
+            zero.x = bc.s1 * bc.c1[r] + bc.s2 * bc.c2[r] * vnext.x;
+            ++r;
+          }
+          if (bits & 2u) zero.y = bc.s1 * bc.c1[r] + bc.s2 * bc.c2[r] * vnext.y;
+        } else {
+          zero = bc.s1 * bc.c1[r] + bc.s2 * bc.c2[r] * vnext;
+        }
+      }
+    }
+  }
+  st(a.b, g, zero);
+}
+
+// nvec entries of width VEC, then `ntail` single entries (at most VEC - 1: the odd last dof of a 16-byte sweep) by
+// the first threads of the last block -- one launch whatever the vector length
+template <int VEC, bool HAS_NEXT, bool NT = false, bool BC = false>
+__global__ void __launch_bounds__(256) k_rk4_stage(int64_t nvec, int ntail, StageArgs a)
+{
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < nvec; g += (int64_t)gridDim.x * blockDim.x)
+    stage_entry<VEC, HAS_NEXT, NT, BC>(a, g, 0);
+  if (VEC > 1 && blockIdx.x == gridDim.x - 1 && (int)threadIdx.x < ntail)
+    stage_entry<1, HAS_NEXT, false, BC>(a, threadIdx.x, (int64_t)VEC * nvec);
 }
 
 }  // namespace wf
@@ -312,44 +386,168 @@ int wf_dot(int64_t n, const double* d_x, const double* d_y, double* d_result, vo
   WF_LAUNCH_CHECK();
   return WF_OK;
 }
-int wf_rk4_stage(int64_t n, double bdt, double adt_next, int has_next, double* d_b, const double* d_m,
-                 const double* d_vn, const double* d_u_read, const double* d_v_read, double* d_u, double* d_v,
-                 const double* d_u0, const double* d_v0, double* d_un, double* d_vn_next, void* stream)
+}  // extern "C"
+
+struct wf_boundary {
+  int64_t n = 0;
+  int32_t nb = 0, n1 = 0, n2 = 0;
+  unsigned long long* d_mask = nullptr;
+  uint32_t* d_prefix = nullptr;
+  double *d_c1 = nullptr, *d_c2 = nullptr;
+  // the plain index form as well (first right-hand side of a run, reference-order loop)
+  int32_t *d_idx1 = nullptr, *d_idx2 = nullptr;
+  double *d_m1 = nullptr, *d_m2 = nullptr;
+};
+
+namespace {
+
+int rk4_stage_impl(int64_t n, double bdt, double adt_next, int has_next, double* d_b, const double* d_m, const double* d_vn,
+                   const double* d_u_read, const double* d_v_read, double* d_u, double* d_v, const double* d_u0,
+                   const double* d_v0, double* d_un, double* d_vn_next, const wf_boundary* bcp, double s1_next, double s2,
+                   void* stream)
 {
   if (n <= 0) return WF_OK;
   WF_REQUIRE(d_b && d_m && d_vn && d_u_read && d_v_read && d_u && d_v, "wf_rk4_stage: null vector");
   WF_REQUIRE(!has_next || (d_u0 && d_v0 && d_un && d_vn_next), "wf_rk4_stage: next-stage vectors missing");
-  MarkerScope mk("wf_rk4_stage");
   WF_REQUIRE(!has_next || d_vn_next != d_vn, "wf_rk4_stage: vn_next must not alias vn");
+  WF_REQUIRE(!bcp || bcp->n == n, "wf_rk4_stage_bc: the boundary plan was built for another vector length");
+  MarkerScope mk("wf_rk4_stage");
   hipStream_t st = (hipStream_t)stream;
   auto aligned = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   bool vec = aligned(d_b) && aligned(d_m) && aligned(d_vn) && aligned(d_u_read) && aligned(d_v_read) && aligned(d_u)
              && aligned(d_v);
   if (has_next) vec = vec && aligned(d_u0) && aligned(d_v0) && aligned(d_un) && aligned(d_vn_next);
-  const int64_t nv = vec ? n / 2 : 0;   // pairs handled by the 16-byte kernel; the rest (at most one entry) scalar
-  constexpr bool nt = true;   // streaming (non-temporal) accesses for everything but un and b (measured 0.155 -> 0.135 ms)
-#define WF_STAGE(VEC, NEXT, cnt, off)                                                                          \
-  if (nt && VEC == 2)                                                                                          \
-    hipLaunchKernelGGL((k_rk4_stage<VEC, NEXT, true>), dim3(capped_grid((cnt), 256)), dim3(256), 0, st, (cnt), bdt, \
-                     adt_next, d_b + (off), d_m + (off), d_vn + (off), d_u_read + (off), d_v_read + (off),      \
-                     d_u + (off), d_v + (off), NEXT ? d_u0 + (off) : nullptr, NEXT ? d_v0 + (off) : nullptr,   \
-                     NEXT ? d_un + (off) : nullptr, NEXT ? d_vn_next + (off) : nullptr);                        \
-  else                                                                                                         \
-  hipLaunchKernelGGL((k_rk4_stage<VEC, NEXT>), dim3(capped_grid((cnt), 256)), dim3(256), 0, st, (cnt), bdt,     \
-                     adt_next, d_b + (off), d_m + (off), d_vn + (off), d_u_read + (off), d_v_read + (off),      \
-                     d_u + (off), d_v + (off), NEXT ? d_u0 + (off) : nullptr, NEXT ? d_v0 + (off) : nullptr,   \
-                     NEXT ? d_un + (off) : nullptr, NEXT ? d_vn_next + (off) : nullptr)
-  if (nv > 0) {
-    if (has_next) WF_STAGE(2, true, nv, 0); else WF_STAGE(2, false, nv, 0);
-    WF_LAUNCH_CHECK();
+  wf::StageArgs a{};
+  a.bdt = bdt;
+  a.adt_next = adt_next;
+  a.b = d_b;
+  a.m = d_m;
+  a.vn = d_vn;
+  a.u_read = d_u_read;
+  a.v_read = d_v_read;
+  a.u_ = d_u;
+  a.v_ = d_v;
+  a.u0 = d_u0;
+  a.v0 = d_v0;
+  a.un = d_un;
+  a.vn_next = d_vn_next;
+  const bool use_bc = bcp && bcp->nb > 0;
+  if (use_bc) {
+    a.bc.mask = bcp->d_mask;
+    a.bc.prefix = bcp->d_prefix;
+    a.bc.c1 = bcp->d_c1;
+    a.bc.c2 = bcp->d_c2;
+    a.bc.s1 = s1_next;
+    a.bc.s2 = s2;
   }
-  const int64_t rest = n - 2 * nv;
-  if (rest > 0) {
-    if (has_next) WF_STAGE(1, true, rest, 2 * nv); else WF_STAGE(1, false, rest, 2 * nv);
-    WF_LAUNCH_CHECK();
+  // 16-byte sweep (streaming accesses for everything but un and b: 0.155 -> 0.135 ms at cfg2) with the odd last dof
+  // in the same launch, or the scalar kernel for unaligned vectors
+  const int64_t nvec = vec ? n / 2 : n;
+  const int ntail = vec ? (int)(n - 2 * nvec) : 0;
+  const unsigned grid = capped_grid(std::max<int64_t>(nvec, 1), 256);
+#define WF_STAGE(VEC, NEXT, NT_, BC_) \
+  hipLaunchKernelGGL((wf::k_rk4_stage<VEC, NEXT, NT_, BC_>), dim3(grid), dim3(256), 0, st, nvec, ntail, a)
+  if (vec) {
+    if (has_next) { if (use_bc) WF_STAGE(2, true, true, true); else WF_STAGE(2, true, true, false); }
+    else          { if (use_bc) WF_STAGE(2, false, true, true); else WF_STAGE(2, false, true, false); }
+  } else {
+    if (has_next) { if (use_bc) WF_STAGE(1, true, false, true); else WF_STAGE(1, true, false, false); }
+    else          { if (use_bc) WF_STAGE(1, false, false, true); else WF_STAGE(1, false, false, false); }
   }
 #undef WF_STAGE
+  WF_LAUNCH_CHECK();
   return WF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int wf_rk4_stage(int64_t n, double bdt, double adt_next, int has_next, double* d_b, const double* d_m,
+                 const double* d_vn, const double* d_u_read, const double* d_v_read, double* d_u, double* d_v,
+                 const double* d_u0, const double* d_v0, double* d_un, double* d_vn_next, void* stream)
+{
+  return rk4_stage_impl(n, bdt, adt_next, has_next, d_b, d_m, d_vn, d_u_read, d_v_read, d_u, d_v, d_u0, d_v0, d_un, d_vn_next,
+                        nullptr, 0.0, 0.0, stream);
+}
+
+int wf_rk4_stage_bc(int64_t n, double bdt, double adt_next, int has_next, double* d_b, const double* d_m,
+                    const double* d_vn, const double* d_u_read, const double* d_v_read, double* d_u, double* d_v,
+                    const double* d_u0, const double* d_v0, double* d_un, double* d_vn_next, const wf_boundary* bc,
+                    double s1_next, double s2, void* stream)
+{
+  WF_REQUIRE(bc != nullptr, "wf_rk4_stage_bc: null boundary plan");
+  return rk4_stage_impl(n, bdt, adt_next, has_next, d_b, d_m, d_vn, d_u_read, d_v_read, d_u, d_v, d_u0, d_v0, d_un, d_vn_next, bc,
+                        s1_next, s2, stream);
+}
+
+int wf_boundary_destroy(wf_boundary* bc)
+{
+  if (!bc) return WF_OK;
+  (void)hipFree(bc->d_mask);
+  (void)hipFree(bc->d_prefix);
+  (void)hipFree(bc->d_c1);
+  (void)hipFree(bc->d_c2);
+  (void)hipFree(bc->d_idx1);
+  (void)hipFree(bc->d_idx2);
+  (void)hipFree(bc->d_m1);
+  (void)hipFree(bc->d_m2);
+  delete bc;
+  return WF_OK;
+}
+
+int wf_boundary_create(int64_t n, int32_t n1, const int32_t* h_idx1, const double* h_m1, int32_t n2, const int32_t* h_idx2,
+                       const double* h_m2, wf_boundary** out)
+{
+  WF_REQUIRE(out && n >= 0 && n1 >= 0 && n2 >= 0, "wf_boundary_create: bad argument");
+  *out = nullptr;
+  WF_REQUIRE((n1 == 0 || (h_idx1 && h_m1)) && (n2 == 0 || (h_idx2 && h_m2)), "wf_boundary_create: null array");
+  for (int32_t i = 0; i < n1; ++i) WF_REQUIRE(h_idx1[i] >= 0 && h_idx1[i] < n, "wf_boundary_create: index out of range");
+  for (int32_t i = 0; i < n2; ++i) WF_REQUIRE(h_idx2[i] >= 0 && h_idx2[i] < n, "wf_boundary_create: index out of range");
+  const size_t nw = (size_t)((n + 63) / 64) + 1;   // + 1: the stage kernel reads two words per wave
+  std::vector<unsigned long long> mask(nw, 0ull);
+  for (int32_t i = 0; i < n1; ++i) mask[h_idx1[i] >> 6] |= 1ull << (h_idx1[i] & 63);
+  for (int32_t i = 0; i < n2; ++i) mask[h_idx2[i] >> 6] |= 1ull << (h_idx2[i] & 63);
+  std::vector<uint32_t> prefix(nw, 0u);
+  uint32_t run = 0;
+  for (size_t w = 0; w < nw; ++w) {
+    prefix[w] = run;
+    run += (uint32_t)__builtin_popcountll(mask[w]);
+  }
+  const int32_t nb = (int32_t)run;
+  auto rank = [&](int32_t d) {
+    return (size_t)prefix[d >> 6] + (size_t)__builtin_popcountll(mask[d >> 6] & ((1ull << (d & 63)) - 1ull));
+  };
+  std::vector<double> c1((size_t)nb, 0.0), c2((size_t)nb, 0.0);
+  for (int32_t i = 0; i < n1; ++i) c1[rank(h_idx1[i])] += h_m1[i];   // a repeated index accumulates, like wf_boundary_apply
+  for (int32_t i = 0; i < n2; ++i) c2[rank(h_idx2[i])] += h_m2[i];
+  std::unique_ptr<wf_boundary, int (*)(wf_boundary*)> bc(new wf_boundary, wf_boundary_destroy);
+  bc->n = n;
+  bc->nb = nb;
+  bc->n1 = n1;
+  bc->n2 = n2;
+  auto up = [](auto** d, const auto* h, size_t cnt) -> int {
+    *d = nullptr;
+    if (cnt == 0) return WF_OK;
+    WF_HIP_CHECK(hipMalloc((void**)d, cnt * sizeof(**d)));
+    WF_HIP_CHECK(hipMemcpy(*d, h, cnt * sizeof(**d), hipMemcpyHostToDevice));
+    return WF_OK;
+  };
+  int rc;
+  if ((rc = up(&bc->d_mask, mask.data(), nw)) != WF_OK || (rc = up(&bc->d_prefix, prefix.data(), nw)) != WF_OK
+      || (rc = up(&bc->d_c1, c1.data(), (size_t)nb)) != WF_OK || (rc = up(&bc->d_c2, c2.data(), (size_t)nb)) != WF_OK
+      || (rc = up(&bc->d_idx1, h_idx1, (size_t)n1)) != WF_OK || (rc = up(&bc->d_m1, h_m1, (size_t)n1)) != WF_OK
+      || (rc = up(&bc->d_idx2, h_idx2, (size_t)n2)) != WF_OK || (rc = up(&bc->d_m2, h_m2, (size_t)n2)) != WF_OK)
+    return rc;
+  *out = bc.release();
+  return WF_OK;
+}
+
+// b[idx1[i]] += s1 m1[i]; b[idx2[i]] += s2 m2[i] v[idx2[i]] from a plan (the first right-hand side of a fused run)
+int wf_boundary_apply_plan(const wf_boundary* bc, double s1, double s2, const double* d_v, double* d_b, void* stream)
+{
+  WF_REQUIRE(bc && d_v && d_b, "wf_boundary_apply_plan: null argument");
+  return wf_boundary_apply(bc->n1, bc->d_idx1, bc->d_m1, s1, bc->n2, bc->d_idx2, bc->d_m2, s2, d_v, d_b, stream);
 }
 
 int wf_boundary_apply(int32_t n1, const int32_t* d_idx1, const double* d_m1, double s1, int32_t n2,

@@ -59,14 +59,58 @@ def boundary_apply(idx1, m1, s1: float, idx2, m2, s2: float, v, b):
 
 
 def rk4_stage(b, m, vn, u_read, v_read, u, v, bdt: float, adt_next: float = 0.0, u0=None, v0=None, un=None,
-              vn_next=None):
-    """Fused stage tail + next stage head (wf_rk4_stage)."""
+              vn_next=None, bc=None, s1_next: float = 0.0, s2: float = 0.0):
+    """Fused stage tail + next stage head (wf_rk4_stage); with bc (a BoundaryPlan) b is left holding the
+    next right-hand side's boundary term instead of zeros (wf_rk4_stage_bc)."""
     has_next = un is not None
     z = 0
+    if bc is not None:
+        check(lib().wf_rk4_stage_bc(b.numel(), float(bdt), float(adt_next), int(has_next), _ptr(b), _ptr(m), _ptr(vn),
+                                    _ptr(u_read), _ptr(v_read), _ptr(u), _ptr(v),
+                                    _ptr(u0) if has_next else z, _ptr(v0) if has_next else z,
+                                    _ptr(un) if has_next else z, _ptr(vn_next) if has_next else z,
+                                    bc._h, float(s1_next), float(s2), _stream(b)))
+        return
     check(lib().wf_rk4_stage(b.numel(), float(bdt), float(adt_next), int(has_next), _ptr(b), _ptr(m), _ptr(vn),
                              _ptr(u_read), _ptr(v_read), _ptr(u), _ptr(v),
                              _ptr(u0) if has_next else z, _ptr(v0) if has_next else z,
                              _ptr(un) if has_next else z, _ptr(vn_next) if has_next else z, _stream(b)))
+
+
+class BoundaryPlan:
+    """wf_boundary_create: the two boundary dof sets of the form L (LinearGLL.hpp:113-115, forms.ufl:19-24) as a
+    bitmap + coefficient arrays, so that the fused RK4 stage can leave the next right-hand side's boundary
+    term in b instead of zeroing it (rk4_stage(..., bc=plan, s1_next=, s2=))."""
+
+    def __init__(self, n: int, idx1, m1, idx2, m2):
+        import ctypes
+
+        import numpy as np
+
+        from . import _lib
+        i1 = np.ascontiguousarray(idx1, dtype=np.int32)
+        i2 = np.ascontiguousarray(idx2, dtype=np.int32)
+        a1 = np.ascontiguousarray(m1, dtype=np.float64)
+        a2 = np.ascontiguousarray(m2, dtype=np.float64)
+        ip = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)) if a.size else None
+        dp = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_double)) if a.size else None
+        self._h = ctypes.c_void_p()
+        check(lib().wf_boundary_create(int(n), i1.size, ip(i1), dp(a1), i2.size, ip(i2), dp(a2), ctypes.byref(self._h)))
+
+    def apply(self, s1: float, s2: float, v, b):
+        """b[idx1] += s1 m1; b[idx2] += s2 m2 v[idx2] (the plain launch)."""
+        check(lib().wf_boundary_apply_plan(self._h, float(s1), float(s2), _ptr(v), _ptr(b), _stream(b)))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib().wf_boundary_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def cg(x, b, A, kmax: int = 50, rtol: float = 1e-8, updater=None, comm=None):

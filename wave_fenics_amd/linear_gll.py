@@ -227,10 +227,13 @@ class LinearGLLOpt:
 
 def _rk4_fused(self, startTime: float, finalTime: float, timeStep: float, max_steps: int | None = None):
     """The same RK4 integration as rk4() (LinearGLL.hpp:198-287) with the vector
-    algebra between two stiffness applies fused into one pass (wf_rk4_stage) and
+    algebra between two stiffness applies fused into one pass (wf_rk4_stage_bc) and
     the stage-0 copies removed by pointer rotation: per stage
-    K (116 B/dof at P4) + 96 B/dof instead of K + 208 B/dof.  Same arithmetic
-    expressions as the unfused loop."""
+    K (116 B/dof at P4) + 96 B/dof instead of K + 208 B/dof.  The diagonal boundary term
+    of the NEXT right-hand side is left in b by the stage kernel (instead of zeros), so a
+    stage is two launches: stiffness apply, fused vector algebra.  Same arithmetic
+    expressions as the unfused loop (b receives the boundary term before the stiffness
+    contributions instead of after them)."""
     from .distributed import overlapped_apply
     t, tf, dt = startTime, finalTime, timeStep
     step = 0
@@ -244,42 +247,56 @@ def _rk4_fused(self, startTime: float, finalTime: float, timeStep: float, max_st
     c_runge = [0.0, 0.5, 0.5, 1.0]
     upd = self.updater
 
-    def rhs(tn, x_u, x_v):
-        """b = K x_u + boundary(x_v) (+ reverse ghost update); b is zero on entry."""
+    def s1(tn):
+        """c0^2 g(t): the coefficient of the Gamma_1 term (LinearGLL.hpp:153-162)."""
         if tn < self.T_ * self.alpha_:
             window = 0.5 * (1.0 - math.cos(self.freq0_ * math.pi * tn / self.alpha_))
         else:
             window = 1.0
-        g = window * self.p0_ * self.w0_ / self.c0_ * math.cos(self.w0_ * tn)
+        return self.c0_ ** 2 * window * self.p0_ * self.w0_ / self.c0_ * math.cos(self.w0_ * tn)
+
+    def rhs(x_u):
+        """b += K x_u (+ ghost updates); b holds the boundary term of this right-hand side on entry."""
         if self._split:
-            # interior cells on the main stream; halo of u, interface cells and the
-            # reverse halo of b beside them on a second stream
+            # interior cells beside the halo of u, the interface cells and the reverse halo of b
             overlapped_apply(self.stiff_op, upd, x_u, b)
-            la.boundary_apply(self.idx1, self.mG1, self.c0_ ** 2 * g, self.idx2, self.mG2, -self.c0_, x_v, b)
             return
         if upd is not None:
             upd.scatter_fwd(x_u)
         self.stiff_op(x_u, b)
-        la.boundary_apply(self.idx1, self.mG1, self.c0_ ** 2 * g, self.idx2, self.mG2, -self.c0_, x_v, b)
         if upd is not None:
             upd.scatter_rev(b)
 
+    if getattr(self, "_bc", None) is None:
+        self._bc = la.BoundaryPlan(b.numel(), self.idx1.cpu().numpy(), self.mG1.cpu().numpy(), self.idx2.cpu().numpy(),
+                                   self.mG2.cpu().numpy())
+    # fold_boundary = False keeps the boundary term a launch of its own after each stage kernel (for comparison)
+    fold = getattr(self, "fold_boundary", True)
+    bc, s2 = self._bc, -self.c0_
     la.fill(b, 0.0)
+    bc.apply(s1(t), s2, v0, b)           # boundary term of the first right-hand side; the stage kernels leave the others
     while t < tf:
         dt = min(dt, tf - t)
         # stage 0: un = u0, vn = v0 (a_0 = 0), read straight from u0 / v0
         x_u, x_v = u0, v0
         vn_next = vn_a
         for i in range(4):
-            rhs(t + c_runge[i] * dt, x_u, x_v)
+            rhs(x_u)
             last = i == 3
             ur, vr = (u0, v0) if i == 0 else (u_, v_)
             if not last:
-                la.rk4_stage(b, m, x_v, ur, vr, u_, v_, dt * b_runge[i], dt * a_runge[i + 1], u0, v0, un, vn_next)
+                la.rk4_stage(b, m, x_v, ur, vr, u_, v_, dt * b_runge[i], dt * a_runge[i + 1], u0, v0, un, vn_next,
+                             bc=bc if fold else None, s1_next=s1(t + c_runge[i + 1] * dt), s2=s2)
+                if not fold:
+                    bc.apply(s1(t + c_runge[i + 1] * dt), s2, vn_next, b)
                 x_u, x_v = un, vn_next
                 vn_next = vn_b if vn_next is vn_a else vn_a
             else:
-                la.rk4_stage(b, m, x_v, ur, vr, u_, v_, dt * b_runge[i])      # also zeroes b
+                # the next right-hand side is stage 0 of the next step: v = the updated solution, time t + dt
+                # (after the last step b is left holding a boundary term nobody reads; f1 / rk4 zero b themselves)
+                la.rk4_stage(b, m, x_v, ur, vr, u_, v_, dt * b_runge[i], bc=bc if fold else None, s1_next=s1(t + dt), s2=s2)
+                if not fold:
+                    bc.apply(s1(t + dt), s2, v_, b)
         u0, u_ = u_, u0          # the new solution becomes the next step's u0
         v0, v_ = v_, v0
         t += dt
