@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libwavehip.so")
-SOURCES = ["tables.cpp", "mesh_io.cpp", "generic_plan.cpp", "function_space.cpp", "markers.cpp", "kernels.hip", "stiffness_march_idx.hip", "stiffness_march.hip", "stiffness_march_ks.hip", "stiffness_dense.hip", "tsmm.hip", "vector_kernels.hip", "comm.hip", "cg.hip", "api.hip"]
+SOURCES = ["tables.cpp", "mesh_io.cpp", "generic_plan.cpp", "function_space.cpp", "markers.cpp", "kernels.hip", "stiffness_march_idx.hip", "stiffness_march.hip", "stiffness_march_ks.hip", "mass_march.hip", "stiffness_dense.hip", "tsmm.hip", "vector_kernels.hip", "comm.hip", "cg.hip", "api.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "stiffness_core.h"),
            os.path.join(ROOT, "include", "wavehip.h")]
 

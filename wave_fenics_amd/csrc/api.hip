@@ -1014,7 +1014,7 @@ int wf_op_apply(wf_op* op, const double* d_x, double* d_y, void* stream)
     case WF_OP_MASS_DENSE:
       if (op->d_mdiag) return wf_pointwise_mult_add(op->ndofs, op->d_mdiag, d_x, d_y, stream);   // collocated rule
       if (op->have_plan == 2)
-        return launch_mass_march_idx(op->P, op->plan, op->d_detJ, op->d_phi1, op->dm, d_x, d_y, s);
+        return launch_mass_march(op->P, op->plan, op->d_detJ, op->d_phi1, d_x, d_y, s);
       if (op->dense_square && op->generic_unique)
         return launch_mass_dense_col(op->P, op->ncells, op->d_uoff, op->d_uniq, op->d_loc, op->d_phi1, op->d_detJ, d_x, d_y,
                                      s);

@@ -121,8 +121,11 @@ constexpr int OP_KIND_STIFFNESS = 0, OP_KIND_MASS = 1;
 void march_idx_shape(int kind, int P, int* bx, int* by);   // stiffness: keeps a compiled (*bx, *by) of the k-split kernel
 size_t march_idx_lds_bytes(int kind, int P, int BX, int BY, int lz);
 size_t march_idx_lds_budget(int kind, int P, int BX, int BY);
-int launch_mass_march_idx(int P, const MarchPlanDev& pd, const double* d_detJblk, const double* d_phi1, const DMat& pm,
-                          const double* d_x, double* d_y, hipStream_t s);
+// dense mass on the lattice columns (mass_march.hip)
+void mass_march_shape(int P, int* bx, int* by);
+size_t mass_march_lds_bytes(int P, int BX, int BY, int lz);
+int launch_mass_march(int P, const MarchPlanDev& pd, const double* d_detJblk, const double* d_phi1, const double* d_x,
+                      double* d_y, hipStream_t s);
 int launch_stiffness_march_idx(int P, const MarchPlanDev& pd, const double* d_G6blk, const double* d_D,
                                const DMat& dm, double coeff, const double* d_x, double* d_y, const int32_t* d_items,
                                int nitems, hipStream_t s);

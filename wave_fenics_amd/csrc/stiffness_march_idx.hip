@@ -15,11 +15,8 @@
 // HBM-bound; algorithmic bytes ncells (48 nq + 4 nd) + 16 ndofs; the index
 // table costs 4 P (P BX + 1)(P BY + 1) / (BX BY) bytes per cell when it is not L2-resident.
 //
-// OP selects the per-cell operator run on every layer:
-//   OP_STIFFNESS  stiffness_column<P> (stiffness_core.h), geometry = 6 doubles per point;
-//   OP_MASS       mass_column<P> below: y += Phi^T (detJ .* (Phi x)) with a square 1-D table
-//                 Phi = phi1 (x) phi1 (x) phi1 (MassOperator::apply, common/cuda/mass.hpp:76-84, the
-//                 DGEMM pair of demo/gpu_operator/main.cpp:144-160), geometry = 1 double per point.
+// Compiled for the stiffness operator at P <= 4 (P >= 5: stiffness_march_ks.hip; the dense mass
+// operator on the same columns: mass_march.hip).
 #include <type_traits>
 
 #include "stiffness_core.h"
@@ -27,79 +24,6 @@
 namespace wf {
 
 constexpr int OP_STIFFNESS = 0, OP_MASS = 1;
-
-// Column-thread core of the dense (sum-factorised) mass operator, the mass counterpart of
-// stiffness_column: thread (i, j) of a cell owns the column (i, j, *).  U: the cell inside the
-// layer's x tile (strides sk, sj); A, B: per-cell LDS scratch [n][n][n]; sP: LDS copy of
-// phi1[q][a]; pm: the same table as scalar operands; dj[k]: detJ * w at the points (i, j, k).
-// Three workgroup barriers inside; the caller provides one before A is written again.
-template <int P>
-__device__ __forceinline__ void mass_column(const double* __restrict__ U, int sk, int sj, double* __restrict__ A,
-                                            double* __restrict__ B, const double* __restrict__ sP, const DMat& pm,
-                                            const double (&dj)[P + 1], int i, int j, bool active, double (&out)[P + 1])
-{
-  constexpr int n = P + 1, n2 = n * n;
-  const int ji = j * n + i;
-  double v[n];
-  if (active) {   // forward x: A[k][j][qi = i] = sum_a phi[i][a] U[k][j][a]
-#pragma unroll
-    for (int k = 0; k < n; ++k) {
-      double s_ = 0.0;
-#pragma unroll
-      for (int a = 0; a < n; ++a) s_ += sP[i * n + a] * U[k * sk + j * sj + a];
-      A[k * n2 + ji] = s_;
-    }
-  }
-  __syncthreads();
-  if (active) {   // forward y (thread = (qi, qj)), forward z, detJ, backward z: registers
-    double vy[n], w[n];
-#pragma unroll
-    for (int k = 0; k < n; ++k) {
-      double s_ = 0.0;
-#pragma unroll
-      for (int a = 0; a < n; ++a) s_ += sP[j * n + a] * A[k * n2 + a * n + i];
-      vy[k] = s_;
-    }
-#pragma unroll
-    for (int q = 0; q < n; ++q) {
-      double s_ = 0.0;
-#pragma unroll
-      for (int k = 0; k < n; ++k) s_ += (P >= 5 ? sP[q * n + k] : pm.v[q * n + k]) * vy[k];   // P >= 5: see below
-      w[q] = s_ * dj[q];
-    }
-#pragma unroll
-    for (int k = 0; k < n; ++k) {
-      double s_ = 0.0;
-#pragma unroll
-      // z-direction entries of phi: kernel-argument constants in SGPRs up to P4; from P5 on 2 n^2 SGPRs are
-      // more than a wave has (176 SGPR spills = v_readlane pairs at P6) -- broadcast reads of the LDS copy instead
-      for (int q = 0; q < n; ++q) s_ += (P >= 5 ? sP[q * n + k] : pm.v[q * n + k]) * w[q];
-      B[k * n2 + ji] = s_;   // B1[k][qj][qi]
-    }
-  }
-  __syncthreads();
-  if (active) {   // backward y: A[k][j][qi = i] = sum_qj phi[qj][j] B1[k][qj][i]
-#pragma unroll
-    for (int k = 0; k < n; ++k) {
-      double s_ = 0.0;
-#pragma unroll
-      for (int q = 0; q < n; ++q) s_ += sP[q * n + j] * B[k * n2 + q * n + i];
-      v[k] = s_;
-    }
-#pragma unroll
-    for (int k = 0; k < n; ++k) A[k * n2 + ji] = v[k];
-  }
-  __syncthreads();
-  if (active) {   // backward x: out[k] = sum_qi phi[qi][i] A[k][j][qi]
-#pragma unroll
-    for (int k = 0; k < n; ++k) {
-      double s_ = 0.0;
-#pragma unroll
-      for (int q = 0; q < n; ++q) s_ += sP[q * n + i] * A[k * n2 + j * n + q];
-      out[k] = s_;
-    }
-  }
-}
 
 // Diagnostic build (tools/march_trace.sh -DWF_IDX_TRACE): per-wave timestamps of the phases of the
 // first layers of the first 512 workgroups, 100 MHz constant clock.
@@ -219,11 +143,6 @@ __global__ __launch_bounds__(256, 2) void k_march_idx(int lz, int tile_size, con
       __syncthreads();
       if (kSpread && has_next && active) load_g(gnext, l + 1, G1, G2);
       stiffness_phase2<P>(Fr + cl * nd, Fs + cl * nd, sD, dm, ft, i, j, active, out);
-    } else {
-      double djk[n];
-#pragma unroll
-      for (int k = 0; k < n; ++k) djk[k] = gcur[k][0];
-      mass_column<P>(Uc, TP, TX, Fr + cl * nd, Fs + cl * nd, sD, dm, djk, i, j, active, out);
     }
     WF_ITR(2);
     double xcp[NCP];
@@ -359,7 +278,11 @@ static bool march_idx_uses_ks(int P) { return P >= 5; }
 void march_idx_shape(int kind, int P, int* bx, int* by)
 {
   static const int kBX[8] = {0, 8, 7, 4, 5, 7, 5, 2}, kBY[8] = {0, 8, 4, 4, 2, 1, 1, 2};
-  if (kind == OP_KIND_STIFFNESS && march_idx_uses_ks(P)) {
+  if (kind == OP_KIND_MASS) {
+    mass_march_shape(P, bx, by);
+    return;
+  }
+  if (march_idx_uses_ks(P)) {
     march_ks_shape(P, bx, by);   // keeps a compiled (*bx, *by), else the degree's default
     return;
   }
@@ -370,7 +293,8 @@ void march_idx_shape(int kind, int P, int* bx, int* by)
 // LDS of one workgroup: the kernel's static arrays + the index tile
 size_t march_idx_lds_bytes(int kind, int P, int BX, int BY, int lz)
 {
-  if (kind == OP_KIND_STIFFNESS && march_idx_uses_ks(P)) return march_ks_lds_bytes(P, BX, BY, lz, true);
+  if (kind == OP_KIND_MASS) return mass_march_lds_bytes(P, BX, BY, lz);
+  if (march_idx_uses_ks(P)) return march_ks_lds_bytes(P, BX, BY, lz, true);
   const int n = P + 1, n2 = n * n, nd = n * n2, CB = BX * BY, TP = (P * BX + 1) * (P * BY + 1);
   return (size_t)((P + 1) * TP + CB * P * n2 + 2 * CB * nd + n * n) * sizeof(double) + (size_t)(P * lz + 1) * TP * sizeof(int32_t);
 }
@@ -398,23 +322,6 @@ int launch_stiffness_march_idx(int P, const MarchPlanDev& pd, const double* d_G6
     case 4: return launch_t<OP_STIFFNESS, 4, 5, 2>(pd, d_G6blk, d_D, dm, coeff, d_x, d_y, d_items, nitems, s);
   }
   set_error("stiffness_march_idx: degree must be 1..7");
-  return WF_ERR_UNSUPPORTED;
-}
-
-// dense mass with a square 1-D table: d_detJblk [item][layer][k][CB n^2] (detJ w at the points), d_phi1 / pm = phi1[q][a]
-int launch_mass_march_idx(int P, const MarchPlanDev& pd, const double* d_detJblk, const double* d_phi1, const DMat& pm,
-                          const double* d_x, double* d_y, hipStream_t s)
-{
-  switch (P) {
-    case 1: return launch_t<OP_MASS, 1, 8, 8>(pd, d_detJblk, d_phi1, pm, 0.0, d_x, d_y, nullptr, 0, s);
-    case 2: return launch_t<OP_MASS, 2, 7, 4>(pd, d_detJblk, d_phi1, pm, 0.0, d_x, d_y, nullptr, 0, s);
-    case 3: return launch_t<OP_MASS, 3, 4, 4>(pd, d_detJblk, d_phi1, pm, 0.0, d_x, d_y, nullptr, 0, s);
-    case 4: return launch_t<OP_MASS, 4, 5, 2>(pd, d_detJblk, d_phi1, pm, 0.0, d_x, d_y, nullptr, 0, s);
-    case 5: return launch_t<OP_MASS, 5, 7, 1>(pd, d_detJblk, d_phi1, pm, 0.0, d_x, d_y, nullptr, 0, s);
-    case 6: return launch_t<OP_MASS, 6, 5, 1>(pd, d_detJblk, d_phi1, pm, 0.0, d_x, d_y, nullptr, 0, s);
-    case 7: return launch_t<OP_MASS, 7, 2, 2>(pd, d_detJblk, d_phi1, pm, 0.0, d_x, d_y, nullptr, 0, s);
-  }
-  set_error("mass_march_idx: degree must be 1..7");
   return WF_ERR_UNSUPPORTED;
 }
 
