@@ -249,12 +249,23 @@ def main():
         # the box kernel addresses the lattice implicitly and never reads the 4*nd dofmap
         # bytes the contract figure includes: also report the fraction on the bytes it must move
         must_move = alg - (4.0 * (p + 1) ** 3 * mesh.ncells if not args.generic else 0.0)
-        traffic = None
+        # HBM traffic of the kernel from the rocprofv3 PMC passes of tools/evidence.sh (not collected in this run);
+        # quoted only when it was measured on THIS build of the library
+        traffic, traffic_note = None, None
         tp = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tp) and p == 4 and n == 54 and not args.generic:
+        if os.path.exists(tp) and p == 4 and n == 54 and not args.generic and tuning is None:
             try:
+                import hashlib
+                from wave_fenics_amd import _lib
+                with open(_lib.LIB_PATH, "rb") as f:
+                    sha = hashlib.sha256(f.read()).hexdigest()[:16]
                 with open(tp) as f:
-                    traffic = json.load(f).get("stiffness_hbm_bytes_per_launch")
+                    tj = json.load(f)
+                if tj.get("lib_sha16") == sha:
+                    traffic = tj.get("stiffness_hbm_bytes_per_launch")
+                    traffic_note = f"static: profiles/traffic.json ({tj.get('tag')}, rocprofv3 --pmc passes on this library build {sha}, not this run)"
+                else:
+                    traffic_note = f"profiles/traffic.json was measured on library build {tj.get('lib_sha16')}, this is {sha}: not quoted"
             except Exception:
                 traffic = None
         out = {
@@ -269,7 +280,7 @@ def main():
                        "kernel": "generic" if args.generic else "box"},
             "roofline": {"bound": "hbm", "kernel": "stiffness apply", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_source": "static: profiles/traffic.json (rocprofv3 --pmc passes, not this run)" if traffic else None,
+                         "traffic_source": traffic_note,
                          "alg_bytes_per_launch": alg, "kernel_ms": kern_ms,
                          "must_move_bytes_per_launch": must_move,
                          "frac_must_move": must_move / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,

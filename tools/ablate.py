@@ -37,19 +37,19 @@ def main():
     ops = {}
     ops["generic"] = w.StiffnessOperator(V, p, structured=False)
     for spec in sys.argv[1:]:
+        # block:bx,by,bz   single-pass block kernel;  march:variant[:lz]   one-thread-per-column marching kernel
+        # (variant 0..2) or the k-split kernel (variant 3);  ks:bx,by[:lz]   k-split kernel with that cross-section
         kind, _, rest = spec.partition(":")
         if kind == "block":
-            os.environ["WF_BOX_KERNEL"] = "block"
-            os.environ["WF_BOX_BLOCK"] = rest
+            tuning = {"kernel": "box_block", "block": tuple(int(v) for v in rest.split(","))}
+        elif kind == "ks":
+            shape, _, lz = rest.partition(":")
+            bx, by = (int(v) for v in shape.split(","))
+            tuning = {"variant": 3, "block": (bx, by, 1), "lz": int(lz or 0)}
         else:
-            os.environ["WF_BOX_KERNEL"] = "march"
             var, _, lz = rest.partition(":")
-            os.environ["WF_MARCH_VARIANT"] = var or "0"
-            if lz:
-                os.environ["WF_MARCH_LZ"] = lz
-            else:
-                os.environ.pop("WF_MARCH_LZ", None)
-        ops[spec] = w.StiffnessOperator(V, p, structured=True)
+            tuning = {"variant": int(var or 0), "lz": int(lz or 0)}
+        ops[spec] = w.StiffnessOperator(V, p, structured=True, tuning=tuning)
     alg = ops["generic"].alg_bytes()
     masks = [int(v) for v in os.environ.get("MASKS", "0,1,2,4,8,3,5,7,15").split(",")]
     print(f"P{p} N{n} ndofs {V.ndofs} alg_bytes {alg/1e6:.1f} MB")

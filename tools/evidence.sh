@@ -1,10 +1,10 @@
 #!/bin/bash
 # Collect the measured evidence of a round on the GPU box (run through gpurun):
-#   bash tools/evidence.sh r02
+#   bash tools/evidence.sh r03
 # Everything lands under gpurun_out/ev_<tag>/ ; tools/summarise_evidence.py turns it into profiles/<tag>_*.
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=$R/gpurun_out/ev_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
@@ -33,10 +33,23 @@ for C in FETCH_SIZE WRITE_SIZE; do
   pmc pmc_generic_$C "$C" "$R/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --generic
 done
 say "all operators"
-python3 "$R/tools/bench_ops.py" stiffness mass dense vector rk4 2>/dev/null > "$OUT/ops.jsonl"
+export DEGREES=2,3,4,5,6,7
+python3 "$R/tools/bench_ops.py" stiffness 2>/dev/null > "$OUT/ops.jsonl"
+export DEGREES=2,4,6
+python3 "$R/tools/bench_ops.py" mass dense vector rk4 2>/dev/null >> "$OUT/ops.jsonl"
 python3 "$R/tools/bench_ops.py" tsmm tet 2>/dev/null >> "$OUT/ops.jsonl"
+python3 "$R/tools/bench_shapes.py" 2>/dev/null > "$OUT/shapes.jsonl"
 prof kt_ops "$R/tools/bench_ops.py" stiffness mass dense
 prof kt_mfma "$R/tools/bench_ops.py" tsmm tet
+say "PMC passes for the other kernels quoted in DESIGN.md (P6 stiffness, dense mass, RK4 stage, tetrahedra)"
+export DEGREES=6
+for C in FETCH_SIZE WRITE_SIZE "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
+  N=$(echo $C | tr ' ' '_' | cut -c1-40)
+  pmc pmc_ops6_$N "$C" "$R/tools/bench_ops.py" stiffness dense
+  pmc pmc_rk4_$N "$C" "$R/tools/bench_rk4.py" --steps 3 --warmup 1
+  pmc pmc_tet_$N "$C" "$R/tools/bench_ops.py" tet
+done
+export DEGREES=2,4,6
 say "MFMA pipe counters"
 pmc pmc_mfma "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "$R/tools/bench_ops.py" tsmm tet
 say "RK4 loop"

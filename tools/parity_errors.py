@@ -17,13 +17,14 @@ for p, n in [(1, (6, 5, 4)), (2, (5, 4, 4)), (3, (5, 3, 3)), (4, (6, 5, 3)), (4,
         x = np.random.default_rng(1).uniform(-1, 1, om.ndofs)
         yref = np.zeros(om.ndofs); K(x, yref)
         row = []
-        for name, kw, env in [("generic(G)", dict(structured=False, G=K.G), {}), ("generic", dict(structured=False), {}),
-                              ("march", dict(structured=True), {}), ("block", dict(structured=True), {"WF_BOX_KERNEL": "block"})]:
-            os.environ.update(env)
+        for name, kw in [("march_idx(G)", dict(structured=False, G=K.G, tuning={"kernel": "march"})),
+                         ("march_idx", dict(structured=False, tuning={"kernel": "march"})),
+                         ("batch", dict(structured=False, tuning={"kernel": "batch"})),
+                         ("march_box", dict(structured=True)), ("box_block", dict(structured=True, tuning={"kernel": "box_block"}))]:
             y = torch.zeros(om.ndofs, dtype=torch.float64, device=dev)
-            w.StiffnessOperator(V, p, {"c0": 1500.0}, **kw)(torch.from_numpy(x).to(dev), y)
-            for k in env: del os.environ[k]
-            row.append(f"{name} {np.abs(y.cpu().numpy() - yref).max() / np.abs(yref).max():.2e}")
+            op = w.StiffnessOperator(V, p, {"c0": 1500.0}, **kw)
+            op(torch.from_numpy(x).to(dev), y)
+            row.append(f"{name}[{op.kernel}] {np.abs(y.cpu().numpy() - yref).max() / np.abs(yref).max():.2e}")
         G, detJ = w.precompute_geometric_data(mesh, p)
         row.append(f"G {np.abs(G - K.G).max() / np.abs(K.G).max():.2e}")
         print(f"P{p} n={n} perturb={perturb}: " + "  ".join(row), flush=True)

@@ -73,7 +73,7 @@ def traffic_block(pm, alg, must, avg_us, label):
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
     src = os.path.join(ROOT, "gpurun_out", f"ev_{tag}")
     dst = os.path.join(ROOT, "profiles")
     os.makedirs(dst, exist_ok=True)
@@ -98,7 +98,7 @@ def main():
     alg = 1187009008.0
     must_box = alg - 4.0 * 125 * 157464
     traffic = {}
-    for kind, key, must in (("box", "k_stiffness_march<", must_box), ("generic", "k_march_idx<0", alg)):
+    for kind, key, must in (("box", "k_stiffness_march<", must_box), ("generic", "k_march_idx<", alg)):
         st = first(os.path.join(src, f"kt_{kind}", "*", "*_kernel_stats.csv"))
         if not st:
             continue
@@ -125,7 +125,11 @@ def main():
                     L.append(f"- {k} / SQ_WAVE_CYCLES = {pm[k]/pm['SQ_WAVE_CYCLES']:.3f}")
         L.append("")
     if "box" in traffic:
+        import hashlib
+        with open(os.path.join(ROOT, "wave_fenics_amd", "libwavehip.so"), "rb") as f:
+            lib_sha = hashlib.sha256(f.read()).hexdigest()[:16]
         out = {"stiffness_hbm_bytes_per_launch": traffic["box"]["hbm_bytes_per_launch"], **traffic["box"], "tag": tag,
+               "lib_sha16": lib_sha,   # bench.py quotes this figure only for the library build it was measured on
                "generic_kernel": traffic.get("generic"),
                "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; KiB -> bytes; FETCH_SIZE x2 "
                          "(gfx950 tallies 128-B requests at 64 B)"}
@@ -144,6 +148,41 @@ def main():
             fr = d.get("frac_of_8TBs")
             fm = d.get("frac_of_f64_mfma_78.6TF", d.get("frac_of_f64_mfma_peak_78.6TF"))
             L.append(f"| {d['op']} | {ms} | " + (f"{fm} of 78.6 TF f64 MFMA" if fm is not None else (f"{fr} of 8 TB/s" if fr is not None else "")) + " |")
+        L.append("")
+    # ---- FETCH / WRITE / LDS / wait counters of the other kernels (separate passes each)
+    groups = (("pmc_ops6_", "P6 stiffness and dense mass (tools/bench_ops.py, DEGREES=6)"), ("pmc_rk4_", "RK4 loop (tools/bench_rk4.py)"),
+              ("pmc_tet_", "tetrahedral kernel (tools/bench_ops.py tet)"))
+    for prefix, title in groups:
+        agg = defaultdict(lambda: defaultdict(list))
+        for cc in glob.glob(os.path.join(src, prefix + "*", "*", "*_counter_collection.csv")):
+            with open(cc) as f:
+                for r in csv.DictReader(f):
+                    nm = short(r["Kernel_Name"])
+                    if nm.startswith("wf::") and "geometry" not in nm:
+                        agg[nm][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        if not agg:
+            continue
+        L += [f"## counters: {title}", "",
+              "traffic = 2 x FETCH_SIZE + WRITE_SIZE (KiB -> bytes; gfx950 tallies the 128-B requests of wide streams at 64 B); "
+              "conflict = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE; wait / active = share of SQ_WAVE_CYCLES.", "",
+              "| kernel | launches | traffic MB | write MB | LDS conflict | wait | issue stall | active |", "|---|---|---|---|---|---|---|---|"]
+        for k, c in sorted(agg.items()):
+            m = {kk: sum(v) / len(v) for kk, v in c.items()}
+            tr = (2.0 * m.get("FETCH_SIZE", 0) + m.get("WRITE_SIZE", 0)) * 1024.0 / 1e6
+            wc = m.get("SQ_WAVE_CYCLES", 0)
+            fmt = lambda a, b: f"{a / b:.3f}" if b else ""
+            L.append(f"| `{k[:64]}` | {len(next(iter(c.values())))} | {tr:.1f} | {m.get('WRITE_SIZE', 0) * 1024 / 1e6:.1f} | "
+                     f"{fmt(m.get('SQ_LDS_BANK_CONFLICT', 0), m.get('SQ_LDS_IDX_ACTIVE', 0))} | {fmt(m.get('SQ_WAIT_ANY', 0), wc)} | "
+                     f"{fmt(m.get('SQ_WAIT_INST_ANY', 0), wc)} | {fmt(m.get('SQ_ACTIVE_INST_ANY', 0), wc)} |")
+        L.append("")
+    p = os.path.join(src, "shapes.jsonl")
+    if os.path.exists(p):
+        shutil.copy(p, os.path.join(dst, f"{tag}_shapes.jsonl"))
+        L += ["## k-split kernel, every compiled cross-section (`tools/bench_shapes.py`)", "", "| P | configuration | ms | of 8 TB/s |", "|---|---|---|---|"]
+        for l in open(p):
+            if l.startswith("{"):
+                d = json.loads(l)
+                L.append(f"| {d['P']} | {d['cfg']} (lz {d['lz']}) | {d['ms']} | {d['frac_8TBs']} |")
         L.append("")
     for nm, title in (("kt_ops", "operators"), ("kt_mfma", "TSMM and tetrahedral kernels"), ("kt_rk4", "RK4 loop (tools/bench_rk4.py, fused)"),
                       ("kt_rk4_periodic", "RK4 loop, periodic xyz partition on one rank (RCCL exchange with itself)")):
