@@ -13,8 +13,12 @@ import wave_fenics_amd as w  # noqa: E402
 
 
 def time_op(op, x, y, reps=15):
-    for _ in range(3):
-        op(x, y)
+    import time
+    t0 = time.time()
+    while time.time() - t0 < 0.15:     # past the power ramp after idle (profiles/r03_power_ramp.md)
+        for _ in range(20):
+            op(x, y)
+        torch.cuda.synchronize()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
     for a, b in ev:
         a.record()

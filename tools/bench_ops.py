@@ -15,9 +15,20 @@ import wave_fenics_amd as w  # noqa: E402
 from wave_fenics_amd import la  # noqa: E402
 
 
-def timeit(fn, reps=20, warm=3):
+def timeit(fn, reps=20, warm=3, settle_s=0.4):
+    """HIP-event median of `reps` calls at the GPU's sustained operating point: after `warm` calls the
+    function is run untimed for `settle_s` seconds, because the first ~60 launches after idle run up to 25 %
+    slower while board power ramps (profiles/r03_power_ramp.md).  SETTLE=0 in the environment times from idle."""
+    import time
     for _ in range(warm):
         fn()
+    torch.cuda.synchronize()
+    settle_s = float(os.environ.get("SETTLE", settle_s))
+    t0 = time.time()
+    while time.time() - t0 < settle_s:
+        for _ in range(20):
+            fn()
+        torch.cuda.synchronize()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
     for a, b in ev:
         a.record()
@@ -159,12 +170,13 @@ def main():
                 eqn = LinearGLLOpt(V2, p, 1500.0, 0.5e6, 6e4)
                 eqn.init()
                 run = eqn.rk4_fused if fused else eqn.rk4
-                run(0.0, 3 * dt - 1e-13, dt)
+                nwarm = 100 if float(os.environ.get("SETTLE", "1")) > 0 else 3   # past the power ramp after idle
+                run(0.0, nwarm * dt - 1e-13, dt)
                 torch.cuda.synchronize()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                nsteps = 20
+                nsteps = 50
                 e0.record()
-                run(3 * dt, (3 + nsteps) * dt - 1e-13, dt)
+                run(nwarm * dt, (nwarm + nsteps) * dt - 1e-13, dt)
                 e1.record()
                 torch.cuda.synchronize()
                 ms = e0.elapsed_time(e1) / nsteps

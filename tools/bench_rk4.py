@@ -19,8 +19,8 @@ sys.path.insert(0, ROOT)
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=150, help="untimed steps; long enough to pass the power ramp after idle (profiles/r03_power_ramp.md)")
     ap.add_argument("--size", type=int, default=54)
     ap.add_argument("--degree", type=int, default=4)
     ap.add_argument("--unfused", action="store_true")

@@ -4,6 +4,7 @@ z segment.  One JSON line per configuration (HIP-event median of 20 applies, int
 import json
 import os
 import sys
+import time
 
 import numpy as np
 import torch
@@ -43,6 +44,11 @@ def main():
         for name, op in ops:
             for _ in range(3):
                 op(x, y)
+        t0 = time.time()
+        while time.time() - t0 < 0.15:     # hold the load past the power ramp after idle (profiles/r03_power_ramp.md)
+            for _ in range(20):
+                ops[0][1](x, y)
+            torch.cuda.synchronize()
         for r in range(5):
             for name, op in ops:
                 ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(4)]

@@ -26,11 +26,11 @@ prof kt_generic "$R/bench.py" --steps 20 --warmup 3 --no-cpu-baseline --generic
 say "PMC passes (box)"
 for C in FETCH_SIZE WRITE_SIZE "TCC_EA0_ATOMIC_sum TCC_HIT_sum TCC_MISS_sum" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "GRBM_GUI_ACTIVE"; do
   N=$(echo $C | tr ' ' '_' | cut -c1-40)
-  pmc pmc_box_$N "$C" "$R/bench.py" --steps 5 --warmup 2 --no-cpu-baseline
+  pmc pmc_box_$N "$C" "$R/bench.py" --steps 5 --warmup 2 --settle-steps 0 --no-cpu-baseline
 done
 say "PMC passes (generic)"
 for C in FETCH_SIZE WRITE_SIZE; do
-  pmc pmc_generic_$C "$C" "$R/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --generic
+  pmc pmc_generic_$C "$C" "$R/bench.py" --steps 5 --warmup 2 --settle-steps 0 --no-cpu-baseline --generic
 done
 say "all operators"
 export DEGREES=2,3,4,5,6,7
@@ -42,7 +42,7 @@ python3 "$R/tools/bench_shapes.py" 2>/dev/null > "$OUT/shapes.jsonl"
 prof kt_ops "$R/tools/bench_ops.py" stiffness mass dense
 prof kt_mfma "$R/tools/bench_ops.py" tsmm tet
 say "PMC passes for the other kernels quoted in DESIGN.md (P6 stiffness, dense mass, RK4 stage, tetrahedra)"
-export DEGREES=6
+export DEGREES=6 SETTLE=0    # counters are per launch: no need to hold the load through the power ramp
 for C in FETCH_SIZE WRITE_SIZE "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
   N=$(echo $C | tr ' ' '_' | cut -c1-40)
   pmc pmc_ops6_$N "$C" "$R/tools/bench_ops.py" stiffness dense
@@ -52,13 +52,16 @@ done
 export DEGREES=2,4,6
 say "MFMA pipe counters"
 pmc pmc_mfma "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "$R/tools/bench_ops.py" tsmm tet
+unset SETTLE
 say "RK4 loop"
 python3 "$R/tools/bench_rk4.py" 2>/dev/null | tail -1 > "$OUT/rk4.jsonl"
 python3 "$R/tools/bench_rk4.py" --unfused 2>/dev/null | tail -1 >> "$OUT/rk4.jsonl"
 python3 "$R/tools/bench_rk4.py" --periodic x 2>/dev/null | tail -1 >> "$OUT/rk4.jsonl"
 python3 "$R/tools/bench_rk4.py" --periodic xyz 2>/dev/null | tail -1 >> "$OUT/rk4.jsonl"
-prof kt_rk4 "$R/tools/bench_rk4.py" --steps 10
-prof kt_rk4_periodic "$R/tools/bench_rk4.py" --steps 10 --periodic xyz
+prof kt_rk4 "$R/tools/bench_rk4.py" --steps 50
+prof kt_rk4_periodic "$R/tools/bench_rk4.py" --steps 50 --periodic xyz
+say "launch durations from idle (power ramp)"
+for a in "4 400 0" "6 400 0" "6 400 100" "7 400 0"; do python3 "$R/tools/drift.py" $a 2>/dev/null; done > "$OUT/power_ramp.log"
 say "generic kernel under hostile orderings"
 python3 "$R/tools/bench_generic_orderings.py" 2>/dev/null > "$OUT/generic_orderings.log"
 say "f64 MFMA rate, HBM read rate, TSMM and tet timelines (diagnostic binaries built beforehand into examples/bin)"
