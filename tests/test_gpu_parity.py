@@ -807,7 +807,11 @@ def test_generic_ops_random_cell_order(gpu, oracle):
 
 @pytest.mark.parametrize("ncells,K,N", [(1000, 125, 125), (37, 27, 27), (513, 64, 64), (100, 8, 8), (77, 35, 192),
                                         (50, 125, 216), (16, 3, 5), (300, 216, 216), (130, 343, 343), (40, 512, 512),
-                                        (64, 129, 40), (33, 216, 125)])
+                                        (64, 129, 40), (33, 216, 125),
+                                        # whole rounds of the persistent grid (2048 waves x 16 cells) + a last round that is
+                                        # split along the columns into units of 1 / 2 column tiles, or too full to split
+                                        (100000, 125, 125), (40000, 125, 125), (60000, 125, 125), (70000, 27, 27),
+                                        (35000, 216, 216), (32768, 64, 64)])
 def test_tsmm_vs_numpy(gpu, ncells, K, N):
     """wf_tsmm in both array layouts (demo/gpu_operator cell-major, demo/gpu_tsmm
     column-major with lda = ncells) against a float64 numpy product: k-ordered

@@ -46,6 +46,9 @@ __device__ unsigned long long g_tsmm_trace_clk[256 * kTsmmWaves * 8];   // shade
 #else
 #define WF_TR(i)
 #endif
+#ifndef WF_TSMM_PRIO
+#define WF_TSMM_PRIO 1
+#endif
 #ifndef WF_TSMM_ABLATE   // diagnostic bit mask: 1 = no A loads in the loop, 2 = no B (LDS) reads, 4 = no stores
 #define WF_TSMM_ABLATE 0
 #endif
@@ -68,6 +71,7 @@ __device__ __forceinline__ T* lane_ptr(T* base, uint32_t byte_offset)
 // against assumes 2.4 GHz.
 template <int NT, int LAYOUT, bool ACC>
 __global__ __launch_bounds__(64 * kTsmmWaves) void k_tsmm(int64_t ncells, int Kfull, int N, int n0, int k0, int K,
+                                              int64_t main_tiles, int tail_ct,
                                               const double* __restrict__ in, const double* __restrict__ phi,
                                               double* __restrict__ out)
 {
@@ -86,8 +90,6 @@ __global__ __launch_bounds__(64 * kTsmmWaves) void k_tsmm(int64_t ncells, int Kf
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int lc = lane & 15, lg = lane >> 4;
   WF_TR(0);
-  // (the first two chunks of A operands are requested before the table fill, so that their HBM
-  // latency overlaps it)
   const double* bp = sphi + lg * NP + lc;   // B operand of k-step ks, tile nt: bp[(4 ks) NP + 16 nt]
   const int64_t ntiles = (ncells + 15) / 16;
   const int64_t tstride = (int64_t)gridDim.x * kTsmmWaves;
@@ -139,6 +141,21 @@ __global__ __launch_bounds__(64 * kTsmmWaves) void k_tsmm(int64_t ncells, int Kf
   };
   const uint32_t st_lane = LAYOUT == 0 ? (uint32_t)(lg * N + lc) * 8u : ((uint32_t)lg * (uint32_t)ncells + (uint32_t)lc) * 8u;
   double a0[CH], a1[CH], a2[CH], pb[2][NT];
+  // table -> LDS, loads first: all of a thread's table loads are issued in one burst BEFORE the first A-operand
+  // prefetches (vmcnt retires in order: with the A loads in front, the LDS stores of the table waited for the
+  // HBM latency of the operands as well -- 5.5 us of prologue at the reference shape).  rows + 4 <= 132, i.e.
+  // at most 5 rows per thread; 4 spare rows because the B prefetch runs one k-step past the table.
+  constexpr int RPT = (4 * 4 * CH + 4 + 4 * kTsmmWaves - 1) / (4 * kTsmmWaves);
+  double tv[RPT][NP / 16];
+#pragma unroll
+  for (int it = 0; it < RPT; ++it) {
+    const int k = (t >> 4) + it * 4 * kTsmmWaves;
+#pragma unroll
+    for (int q = 0; q < NP / 16; ++q) {
+      const int n = (t & 15) + 16 * q;
+      tv[it][q] = (k < K && n < NW && n0 + n < N) ? phi[(size_t)(k0 + k) * N + n0 + n] : 0.0;
+    }
+  }
   pf_setup();
 #pragma unroll
   for (int q = 0; q < CH; ++q) a0[q] = a_load(q);
@@ -147,18 +164,14 @@ __global__ __launch_bounds__(64 * kTsmmWaves) void k_tsmm(int64_t ncells, int Kf
 #pragma unroll
   for (int q = 0; q < CH; ++q) a1[q] = a_load(q);
   pf_advance();
-  // table -> LDS: 16 lanes per row segment, all loads of a row in flight together, no integer
-  // division (this prologue is a fixed cost of every launch: 18 432 entries at the reference shape;
-  // as a load -> store chain per entry it took ~35 us of the 106 us kernel)
-  for (int k = t >> 4; k < rows + 4; k += 4 * kTsmmWaves) {   // 4 spare rows: the B prefetch runs one k-step past the table
-    double v[NP / 16];
+  // table registers -> LDS (the A prefetches issued after the table loads stay in flight: loads retire in order)
 #pragma unroll
-    for (int q = 0; q < NP / 16; ++q) {
-      const int n = (t & 15) + 16 * q;
-      v[q] = (k < K && n < NW && n0 + n < N) ? phi[(size_t)(k0 + k) * N + n0 + n] : 0.0;
+  for (int it = 0; it < RPT; ++it) {
+    const int k = (t >> 4) + it * 4 * kTsmmWaves;
+    if (k < rows + 4) {
+#pragma unroll
+      for (int q = 0; q < NP / 16; ++q) sphi[k * NP + (t & 15) + 16 * q] = tv[it][q];
     }
-#pragma unroll
-    for (int q = 0; q < NP / 16; ++q) sphi[k * NP + (t & 15) + 16 * q] = v[q];
   }
   __syncthreads();
   WF_TR(1);
@@ -169,6 +182,12 @@ __global__ __launch_bounds__(64 * kTsmmWaves) void k_tsmm(int64_t ncells, int Kf
   // one chunk: MFMAs on `cur`, loads of the chunk two ahead into `nn`
   auto chunk = [&](const double (&cur)[CH], double (&nn)[CH]) {
     const int64_t c0 = tile * 16;
+#if WF_TSMM_PRIO
+    // the two waves of a SIMD take turns at the higher issue priority, chunk by chunk (the arbiter otherwise
+    // favours the older wave: tools/tsmm_trace.hip shows wave 0 done with its tiles 15 us before wave 4)
+    if ((ch ^ (swave >> 2)) & 1) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);
+#endif
     if (ch == 0) {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) acc[nt] = double4_t{0.0, 0.0, 0.0, 0.0};
@@ -259,12 +278,94 @@ __global__ __launch_bounds__(64 * kTsmmWaves) void k_tsmm(int64_t ncells, int Kf
       tile += tstride;
     }
   };
-  while (tile < ntiles) {
+  while (tile < main_tiles) {
     chunk(a0, a2);
-    if (tile >= ntiles) break;
+    if (tile >= main_tiles) break;
     chunk(a1, a0);
-    if (tile >= ntiles) break;
+    if (tile >= main_tiles) break;
     chunk(a2, a1);
+  }
+  // Tail: the cell tiles [main_tiles, ntiles) of a partial last round, split along the columns into units of
+  // CT column tiles so that every SIMD gets at most one unit.  The kernel is MFMA-bound per SIMD (a tile is
+  // 32 k-steps x 8 column tiles x 64.6 cycles = 7.9 us at 2.1 GHz), and at the reference's 100 000 cells
+  // (6250 tiles = 6 per SIMD + 106) the SIMDs that ran a seventh whole tile set the kernel's duration:
+  // tools/tsmm_trace.hip showed 69 us with 55 us of MFMA work on those SIMDs.  As 848 eighth-tiles the
+  // remainder costs every SIMD 1 us.  A unit loads the tile's A operands in one burst (<= 32 per lane).
+  if (tail_ct > 0) {
+    auto tail = [&](auto ct_tag) {
+      constexpr int CT = decltype(ct_tag)::value;
+      constexpr int UP = (NT + CT - 1) / CT;   // units per cell tile
+      const int64_t unit = first_tile;
+      if (unit >= (ntiles - main_tiles) * UP) return;
+      const int64_t tl = main_tiles + unit / UP;
+      const int ntb = __builtin_amdgcn_readfirstlane((int)(unit % UP) * CT);
+      const int64_t c0 = tl * 16;
+      const int lcp = std::min(lc, (int)(cmax - c0));
+      const double* base = LAYOUT == 0 ? in + c0 * Kfull + k0 : in + (int64_t)k0 * ncells + c0;
+      const uint32_t off = LAYOUT == 0 ? (uint32_t)(lcp * Kfull) : (uint32_t)lcp;
+      double a[4 * CH];
+#pragma unroll
+      for (int q = 0; q < 4 * CH; ++q) {
+        const int kse = std::min(q, ksmax);
+        const int lgp = std::min(lg, K - 1 - 4 * kse);
+        a[q] = LAYOUT == 0 ? *lane_ptr(base + 4 * kse, (off + (uint32_t)lgp) * 8u)
+                           : *lane_ptr(base + (int64_t)(4 * kse) * ncells, ((uint32_t)lgp * (uint32_t)ncells + off) * 8u);
+      }
+      double4_t tacc[CT];
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        tacc[c] = double4_t{0.0, 0.0, 0.0, 0.0};
+        if (ACC && ntb + c < NT) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if (LAYOUT == 0) {
+              const int64_t cc = c0 + lg + 4 * r;
+              const int n = n0 + 16 * (ntb + c) + lc;
+              if (cc < ncells && n < N) tacc[c][r] = out[cc * N + n];
+            } else {
+              const int n = n0 + 16 * (ntb + c) + lg + 4 * r;
+              const int64_t cc = c0 + lc;
+              if (cc < ncells && n < N) tacc[c][r] = out[(int64_t)n * ncells + cc];
+            }
+          }
+        }
+      }
+      const double* bt = bp + 16 * ntb;
+#pragma unroll
+      for (int q = 0; q < 4 * CH; ++q) {
+        if (q < nch * CH) {   // the LDS table has 4 CH nch (+ 4) rows
+#pragma unroll
+          for (int c = 0; c < CT; ++c) {
+            if (ntb + c < NT) {
+              const double b = bt[(4 * q) * NP + 16 * c];
+              if (LAYOUT == 0) tacc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b, tacc[c], 0, 0, 0);
+              else tacc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(b, a[q], tacc[c], 0, 0, 0);
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        if (ntb + c < NT) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if (LAYOUT == 0) {
+              const int64_t cc = c0 + lg + 4 * r;
+              const int n = n0 + 16 * (ntb + c) + lc;
+              if (cc < ncells && n < N) out[cc * N + n] = tacc[c][r];
+            } else {
+              const int n = n0 + 16 * (ntb + c) + lg + 4 * r;
+              const int64_t cc = c0 + lc;
+              if (cc < ncells && n < N) out[(int64_t)n * ncells + cc] = tacc[c][r];
+            }
+          }
+        }
+      }
+    };
+    if (tail_ct == 1) tail(std::integral_constant<int, 1>{});
+    else if (tail_ct == 2) tail(std::integral_constant<int, 2>{});
+    else tail(std::integral_constant<int, 4>{});
+    WF_TR(trace_slot);
   }
 }
 
@@ -282,12 +383,23 @@ static int launch_tsmm_t(int layout, int64_t ncells, int Kfull, int N, int n0, i
   }
   const int64_t ntiles = (ncells + 15) / 16;
   const unsigned nb = (unsigned)std::min<int64_t>(ntiles, 256);   // one workgroup per CU; small problems spread over CUs first
+  // partial last round: split its tiles along the columns when every wave then gets at most one unit
+  const int64_t nwaves = (int64_t)nb * kTsmmWaves, rem = ntiles % nwaves;
+  int64_t main_tiles = ntiles;
+  int tail_ct = 0;
+  if (rem > 0 && KT <= 4 * kTsmmChunk)
+    for (int ct : {1, 2, 4})
+      if (ct < NT && rem * ((NT + ct - 1) / ct) <= nwaves) {
+        tail_ct = ct;
+        main_tiles = ntiles - rem;
+        break;
+      }
   auto go = [&](auto kern, size_t& set) -> int {
     if (lds > 64 * 1024 && lds > set) {
       WF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       set = lds;
     }
-    hipLaunchKernelGGL(kern, dim3(nb), dim3(64 * kTsmmWaves), lds, s, ncells, Kfull, N, n0, k0, K, in, phi, out);
+    hipLaunchKernelGGL(kern, dim3(nb), dim3(64 * kTsmmWaves), lds, s, ncells, Kfull, N, n0, k0, K, main_tiles, tail_ct, in, phi, out);
     return WF_OK;
   };
   static size_t set[4] = {0, 0, 0, 0};
