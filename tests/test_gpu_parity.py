@@ -303,6 +303,33 @@ def test_dense_mass_vs_oracle(gpu, oracle, p, variant, quad, qd):
     assert np.abs(G - np.swapaxes(G, 2, 3)).max() <= 1e-14 * np.abs(G).max()
 
 
+@pytest.mark.parametrize("p,block,lz", [(2, None, 0), (2, None, 5), (3, None, 4), (4, None, 0), (4, (2, 2), 13), (4, None, 3),
+                                        (5, None, 6), (6, None, 0), (6, (2, 1), 5), (7, None, 13)])
+def test_dense_mass_long_columns(gpu, oracle, p, block, lz):
+    """k_mass_march on columns of 13 layers: the index table streams through its LDS ring (4 P + 1 planes, so it
+    wraps from the fourth layer on), the flush of a layer runs inside the next one, and the last segment is
+    shorter than the others -- both compiled cross-sections of P4 / P6, several segment lengths."""
+    import wave_fenics_amd as w
+    n = (3, 2, 13)
+    om, mesh, V = make(oracle, n, p)
+    pts, wts, phi1, phi, X, W = oracle.tabulate_mass_tables(p, "equispaced", "gauss_jacobi", 2 * p)
+    detJ = oracle.compute_detJ_generic(om, X, W)
+    rng = np.random.default_rng(p + lz)
+    x = rng.uniform(-1, 1, om.ndofs)
+    yref = np.zeros(om.ndofs)
+    oracle.dense_mass_apply(om, phi, detJ, x, yref)
+    tun = {"lz": lz, "kernel": "march"}     # (a 3 x 2 column fills less than half of the low degrees' cross-sections)
+    if block:
+        tun["block"] = (*block, 1)
+    op = w.MassOperator(V, p, phi1, detJ, tuning=tun)
+    assert op.kernel == "march_idx" and (lz == 0 or op.info.plan_lz == lz)
+    y = dev(np.zeros(om.ndofs), gpu)
+    op.apply(dev(x, gpu), y)
+    assert relerr(y.cpu().numpy(), yref) <= TOL
+    op.apply(dev(x, gpu), y)     # y += : a second apply doubles the result (the LDS tiles start from zero again)
+    assert relerr(y.cpu().numpy(), 2 * yref) <= TOL
+
+
 @pytest.mark.parametrize("p", [2, 3, 4])
 def test_x_slowest_tensor_order(gpu, oracle, p):
     """The DOLFINx-facing axis-order hazard: a caller whose tensor index is x-SLOWEST

@@ -456,8 +456,8 @@ int wf_op_create(const wf_op_desc* desc, wf_op** out)
     march_idx_shape(pkind, P, &BX, &BY);
     const int CB = BX * BY, NTq = CB * n * n;
     // layers per work item: as many as the kernel's LDS budget per workgroup allows, at most 16
-    int lz_max = 16;
-    while (lz_max > 1 && march_idx_lds_bytes(pkind, P, BX, BY, lz_max) > march_idx_lds_budget(pkind, P, BX, BY)) --lz_max;
+    int lz_max = plan_mass ? 32 : 16;   // (the dense-mass kernel streams its index table: no LDS limit)
+    while (!plan_mass && lz_max > 1 && march_idx_lds_bytes(pkind, P, BX, BY, lz_max) > march_idx_lds_budget(pkind, P, BX, BY)) --lz_max;
     const int use_fabs = (desc->flags & WF_FLAG_NO_FABS) ? 0 : 1;
     const int clamp = (desc->flags & WF_FLAG_NO_CLAMP) ? 0 : 1;
     // A cell may be looked at with an axis reversed only if the 1-D table reads the same backwards,
