@@ -38,6 +38,9 @@ namespace wf {
 //    instead of the round-robin order: 0.247 ms.
 // Diagnostic build (tools/march_trace.sh): per-wave timestamps of the phases of the first layers of
 // the first 512 workgroups, 100 MHz constant clock.
+#ifndef WF_MARCH_TILE_ADD
+#define WF_MARCH_TILE_ADD 1
+#endif
 #ifdef WF_MARCH_TRACE
 constexpr int kMarchTraceIters = 12, kMarchTraceSlots = 6;
 __device__ unsigned long long g_march_trace[512 * 4 * kMarchTraceIters * kMarchTraceSlots];
@@ -66,7 +69,14 @@ __global__ __launch_bounds__(256, 2) void k_stiffness_march(int nx, int ny, int 
   static_assert(NT <= 256, "column does not fit a 256-thread workgroup");
 
   __shared__ __attribute__((aligned(16))) double Ux[(P + 1) * TP];   // x planes of the layer
+#if WF_MARCH_TILE_ADD
+  // results of the layer's cells, summed where they share a face (ds_add_f64): planes 0..P-1 of the tile.  The
+  // flush of a position is then one LDS read (+ the zero for the next layer) and one global atomic; as a gather
+  // over the (up to four) cells' private results it decoded its position and took four guarded LDS reads.
+  __shared__ __attribute__((aligned(16))) double O[P * TP > CB * n2 ? P * TP : CB * n2];
+#else
   __shared__ __attribute__((aligned(16))) double O[CB * P * n2];     // per-cell results, planes 0..P-1
+#endif
   __shared__ __attribute__((aligned(16))) double Fr[CB * nd];
   __shared__ __attribute__((aligned(16))) double Fs[CB * nd];
   __shared__ __attribute__((aligned(16))) double sD[n * n];
@@ -132,6 +142,9 @@ __global__ __launch_bounds__(256, 2) void k_stiffness_march(int nx, int ny, int 
   double2 gA[n][3], gB[n][3];
   load_g(gA, z0);
   if (t < n * n) sD[t] = dD[t];
+#if WF_MARCH_TILE_ADD
+  for (int e = t; e < P * TP; e += 256) O[e] = 0.0;
+#endif
   {
     const size_t base = plane * (size_t)(P * z0);
 #pragma unroll
@@ -201,8 +214,14 @@ __global__ __launch_bounds__(256, 2) void k_stiffness_march(int nx, int ny, int 
     if (active) {
       out[0] += carry;        // z-shared plane: partial sum of the layer below
       carry = out[P];
+#if WF_MARCH_TILE_ADD
+      double* To = O + (P * ly + j) * TX + P * lx + i;
+#pragma unroll
+      for (int k = 0; k < P; ++k) __hip_atomic_fetch_add(To + k * TP, out[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
 #pragma unroll
       for (int k = 0; k < P; ++k) O[(cl * P + k) * n2 + ji] = out[k];
+#endif
     }
     __syncthreads();
     WF_MTR(3);
@@ -229,6 +248,15 @@ __global__ __launch_bounds__(256, 2) void k_stiffness_march(int nx, int ny, int 
     // (d) combine the cells of the layer (fixed order) and add the finished planes to y
 #pragma unroll
     for (int m = 0; m < NPOS; ++m) {
+#if WF_MARCH_TILE_ADD
+      const int pos = t + 256 * m;
+      double v = 0.0;
+      if (pos < P * TP) {
+        v = O[pos];
+        O[pos] = 0.0;
+      }
+      if (poff[m] < 0) continue;
+#else
       if (poff[m] < 0) continue;
       const int pos = t + 256 * m;
       const int pl = pos / TP, r = pos % TP, J = r / TX, I = r % TX;
@@ -242,6 +270,7 @@ __global__ __launch_bounds__(256, 2) void k_stiffness_march(int nx, int ny, int 
         if (ca < BX) v += O[(((cb - 1) * BX + ca) * P + pl) * n2 + P * n + ia];
         if (ia == 0 && ca > 0) v += O[(((cb - 1) * BX + ca - 1) * P + pl) * n2 + P * n + P];
       }
+#endif
       double* dst = y + base + poff[m];
       if (ablate & 1) {
         if (v == 1.2345e300) *dst = v;

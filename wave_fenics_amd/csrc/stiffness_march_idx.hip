@@ -56,7 +56,9 @@ __global__ __launch_bounds__(256, 2) void k_march_idx(int lz, int tile_size, con
   static_assert(NT <= 256, "column does not fit a 256-thread workgroup");
 
   __shared__ __attribute__((aligned(16))) double Ux[(P + 1) * TP];   // x planes of the layer
-  __shared__ __attribute__((aligned(16))) double O[CB * P * n2];     // per-cell results, planes 0..P-1
+  // results of the layer's cells, summed where they share a face (ds_add_f64): planes 0..P-1 of the tile
+  // (see stiffness_march.hip); reused for the carried plane in the epilogue
+  __shared__ __attribute__((aligned(16))) double O[P * TP > CB * n2 ? P * TP : CB * n2];
   __shared__ __attribute__((aligned(16))) double Fr[CB * nd];
   __shared__ __attribute__((aligned(16))) double Fs[CB * nd];
   __shared__ __attribute__((aligned(16))) double sD[n * n];
@@ -100,6 +102,7 @@ __global__ __launch_bounds__(256, 2) void k_march_idx(int lz, int tile_size, con
   // index table first (L2-resident for regular numberings), then the first layer's geometry and
   // x planes together: one HBM latency in the prologue, not two (loads retire in order)
   if (t < n * n) sD[t] = dD[t];
+  for (int e = t; e < P * TP; e += 256) O[e] = 0.0;
   for (int e = t; e < (P * nl + 1) * TP; e += 256) sIdx[e] = pat[e];
   __syncthreads();
   if (active) load_g(gA, 0);
@@ -154,8 +157,9 @@ __global__ __launch_bounds__(256, 2) void k_march_idx(int lz, int tile_size, con
     if (active) {
       out[0] += carry;        // z-shared plane: partial sum of the layer below
       carry = out[P];
+      double* To = O + (P * ly + j) * TX + P * lx + i;
 #pragma unroll
-      for (int k = 0; k < P; ++k) O[(cl * P + k) * n2 + ji] = out[k];
+      for (int k = 0; k < P; ++k) __hip_atomic_fetch_add(To + k * TP, out[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     __syncthreads();
     WF_ITR(3);
@@ -184,18 +188,9 @@ __global__ __launch_bounds__(256, 2) void k_march_idx(int lz, int tile_size, con
       const int pos = t + 256 * m;
       if (pos >= P * TP) continue;
       const int32_t off = sIdx[(P * l) * TP + pos];
+      const double v = O[pos];
+      O[pos] = 0.0;
       if (off < 0) continue;
-      const int pl = pos / TP, r = pos % TP, J = r / TX, I = r % TX;
-      const int ca = I / P, ia = I % P, cb = J / P, jb = J % P;
-      double v = 0.0;
-      if (cb < BY) {
-        if (ca < BX) v += O[((cb * BX + ca) * P + pl) * n2 + jb * n + ia];
-        if (ia == 0 && ca > 0) v += O[((cb * BX + ca - 1) * P + pl) * n2 + jb * n + P];
-      }
-      if (jb == 0 && cb > 0) {
-        if (ca < BX) v += O[(((cb - 1) * BX + ca) * P + pl) * n2 + P * n + ia];
-        if (ia == 0 && ca > 0) v += O[(((cb - 1) * BX + ca - 1) * P + pl) * n2 + P * n + P];
-      }
       unsafeAtomicAdd(y + gbase + off, v);
     }
     };

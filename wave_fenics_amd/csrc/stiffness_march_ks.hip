@@ -110,8 +110,8 @@ struct KSLayout {
   static constexpr int TH = ((NTc + 63) / 64) * 64, WG = 2 * TH;
   static constexpr int TX = P * BX + 1, TY = P * BY + 1, TP = TX * TY;
   static constexpr int oUx = 0;                          // [2][(P + 1) TP]
-  static constexpr int oO = oUx + 2 * (P + 1) * TP;      // [2][CB P n2]
-  static constexpr int oCy = oO + 2 * CB * P * n2;       // [2][NTc]
+  static constexpr int oO = oUx + 2 * (P + 1) * TP;      // [2][P TP] result tile of a layer, the cells' contributions summed (ds_add_f64)
+  static constexpr int oCy = oO + 2 * P * TP;            // [2][NTc]
   static constexpr int oFr = oCy + 2 * NTc;              // [CB nd] x 3
   static constexpr int oD = oFr + 3 * CB * nd;           // [2][n n]: D and its transpose
   static constexpr int ndoubles = ((oD + 2 * n * n + 1) / 2) * 2;
@@ -121,7 +121,7 @@ struct KSLayout {
 size_t march_ks_lds_bytes(int P, int BX, int BY, int lz, bool idx)
 {
   const int n = P + 1, n2 = n * n, nd = n * n2, CB = BX * BY, TP = (P * BX + 1) * (P * BY + 1);
-  size_t d = (size_t)2 * (P + 1) * TP + (size_t)2 * CB * P * n2 + (size_t)2 * CB * n2 + (size_t)3 * CB * nd + 2 * n * n + 2;
+  size_t d = (size_t)2 * (P + 1) * TP + (size_t)2 * P * TP + (size_t)2 * CB * n2 + (size_t)3 * CB * nd + 2 * n * n + 2;
   return d * sizeof(double) + (idx ? (size_t)(P * lz + 1) * TP * sizeof(int32_t) : 0);
 }
 
@@ -245,16 +245,21 @@ __device__ __forceinline__ void ks_march(const KSArgs& a, const DMat& dm, double
     }
   }
   if (H == 1 && active) Cy[NTc + tc] = 0.0;   // carry into the first layer (buffer of "layer -1")
+  for (int e = t; e < 2 * P * TP; e += WG) O[e] = 0.0;
   __syncthreads();
 
   const int ucell = (P * ly) * TX + P * lx;
 
-  // flush of the planes a layer has finished: combine the cells (fixed order) and add to y
-  auto flush = [&](const double* Ob, int l) {
+  // flush of the planes a layer has finished: the cells' contributions were summed in the LDS tile by phase 2
+  // (ds_add_f64), so a position is one LDS read (+ the zero for the tile's next use) and one global atomic (as a
+  // gather over the up to four cells' private results the flush decoded its position and took four guarded reads)
+  auto flush = [&](double* Tb, int l) {
 #pragma unroll
     for (int m = 0; m < NPOS; ++m) {
       const int pos = t + WG * m;
       if (pos >= P * TP) continue;
+      const double v = Tb[pos];
+      Tb[pos] = 0.0;
       size_t dst;
       if constexpr (IDX) {
         const int32_t off = sIdx[(P * l) * TP + pos];
@@ -263,17 +268,6 @@ __device__ __forceinline__ void ks_march(const KSArgs& a, const DMat& dm, double
       } else {
         if (poff[m] < 0) continue;
         dst = plane * (size_t)(P * (z0 + l)) + gbase + poff[m];
-      }
-      const int pl = pos / TP, r = pos % TP, J = r / TX, I = r % TX;
-      const int ca = I / P, ia = I % P, cb = J / P, jb = J % P;
-      double v = 0.0;
-      if (cb < BY) {
-        if (ca < BX) v += Ob[((cb * BX + ca) * P + pl) * n2 + jb * n + ia];
-        if (ia == 0 && ca > 0) v += Ob[((cb * BX + ca - 1) * P + pl) * n2 + jb * n + P];
-      }
-      if (jb == 0 && cb > 0) {
-        if (ca < BX) v += Ob[(((cb - 1) * BX + ca) * P + pl) * n2 + P * n + ia];
-        if (ia == 0 && ca > 0) v += Ob[(((cb - 1) * BX + ca - 1) * P + pl) * n2 + P * n + P];
       }
       unsafeAtomicAdd(a.y + dst, v);
     }
@@ -317,7 +311,7 @@ __device__ __forceinline__ void ks_march(const KSArgs& a, const DMat& dm, double
     const bool has_next = l + 1 < nl, has_next2 = l + 2 < nl;
     const double* Ub = Ux + b * (P + 1) * TP;
     double* Un = Ux + (b ^ 1) * (P + 1) * TP;
-    double* Ob = O + b * (CB * P * n2);
+    double* Tb = O + b * (P * TP);
     const int ln = has_next ? l + 1 : l;
     if constexpr (!EARLY) {
       load_x(ln);
@@ -338,7 +332,7 @@ __device__ __forceinline__ void ks_march(const KSArgs& a, const DMat& dm, double
 #pragma unroll
       for (int k = K0; k < K1; ++k) {
         if (k < P)
-          Ob[(cl * P + k) * n2 + ji] = out[k - K0];
+          __hip_atomic_fetch_add(Tb + k * TP + ucell + j * TX + i, out[k - K0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         else
           Cy[b * NTc + tc] = out[k - K0];
       }
@@ -372,7 +366,7 @@ __device__ __forceinline__ void ks_march(const KSArgs& a, const DMat& dm, double
       if (has_next2) load_g(gcur, l2, 0, G1);
     }
     // (e) flush: runs beside the next layer's phase 1 (no barrier in between)
-    flush(Ob, l);
+    flush(Tb, l);
   };
   for (int l = 0; l < nl; l += 2) {
     layer(gA, gB, l, 0);
