@@ -143,6 +143,10 @@ struct KSArgs {
   double* y;
 };
 
+#ifndef WF_KS_FLUSH_SPLIT
+#define WF_KS_FLUSH_SPLIT 0
+#endif
+
 template <int P, int BX, int BY, bool IDX, int H>
 __device__ __forceinline__ void ks_march(const KSArgs& a, const DMat& dm, double* smem)
 {
@@ -253,9 +257,10 @@ __device__ __forceinline__ void ks_march(const KSArgs& a, const DMat& dm, double
   // flush of the planes a layer has finished: the cells' contributions were summed in the LDS tile by phase 2
   // (ds_add_f64), so a position is one LDS read (+ the zero for the tile's next use) and one global atomic (as a
   // gather over the up to four cells' private results the flush decoded its position and took four guarded reads)
-  auto flush = [&](double* Tb, int l) {
+  auto flush = [&](double* Tb, int l, int m0, int m1) {
 #pragma unroll
     for (int m = 0; m < NPOS; ++m) {
+      if (m < m0 || m >= m1) continue;
       const int pos = t + WG * m;
       if (pos >= P * TP) continue;
       const double v = Tb[pos];
@@ -317,11 +322,19 @@ __device__ __forceinline__ void ks_march(const KSArgs& a, const DMat& dm, double
       load_x(ln);
       if (has_next) load_g(gnext, ln, 0, G1);
     }
+    // Diagnostic switch, measured and not adopted: the flush of layer l - 1 (the other tile buffer) issued inside
+    // layer l -- FS = 1 all of it in front of phase 1, FS = 2 half there and half behind barrier A -- instead of at
+    // the end of its own layer (FS = 0).  Within +-1 % for the box operators, 3-6 % slower for the indexed P5 ones
+    // (tools/variant_lib.sh + bench_shapes.py); it is what made the dense-mass kernel 20 % faster (mass_march.hip).
+    constexpr int FS = WF_KS_FLUSH_SPLIT;
+    constexpr int NPA = FS == 2 ? (NPOS + 1) / 2 : NPOS;
+    if (FS > 0 && l > 0) flush(O + (b ^ 1) * (P * TP), l - 1, 0, NPA);
 
     // (a) phase 1
     if (active) ks_phase1<P, H>(Ub + ucell, TP, TX, Fr + cl * nd, Fs + cl * nd, Ft + cl * nd, sD, dm, gcur, a.coeff, i, j);
     __syncthreads();   // barrier A
     if (has_next) load_g(gnext, ln, G1, NK);
+    if (FS == 2 && l > 0) flush(O + (b ^ 1) * (P * TP), l - 1, NPA, NPOS);
 
     // (b) phase 2; results of planes 0..P-1 -> O, plane P -> carry; the z-shared plane picks up the
     // carry the upper half left in the previous layer
@@ -366,14 +379,15 @@ __device__ __forceinline__ void ks_march(const KSArgs& a, const DMat& dm, double
       if (has_next2) load_g(gcur, l2, 0, G1);
     }
     // (e) flush: runs beside the next layer's phase 1 (no barrier in between)
-    flush(Tb, l);
+    if (FS == 0) flush(Tb, l, 0, NPOS);
   };
   for (int l = 0; l < nl; l += 2) {
     layer(gA, gB, l, 0);
     if (l + 1 < nl) layer(gB, gA, l + 1, 1);
   }
 
-  // ---- epilogue: the last (carried) plane ---------------------------------------------------
+  // ---- epilogue: the last layer's tile (unless flushed already) and the last (carried) plane --------
+  if (WF_KS_FLUSH_SPLIT > 0) flush(O + ((nl - 1) & 1) * (P * TP), nl - 1, 0, NPOS);
   {
     const double* Cb = Cy + ((nl - 1) & 1) * NTc;   // written before barrier B of the last layer
 #pragma unroll
