@@ -36,8 +36,8 @@ def main():
             for (bx, by) in SHAPES[p]:
                 for lz in lzs:
                     t = {"block": (bx, by, 1), "lz": lz}
-                    if p <= 4 and mode == "box":
-                        t["variant"] = 3      # P <= 4 box operators default to k_stiffness_march; 3 selects the k-split kernel
+                    if p == 4 and mode == "box":
+                        t["variant"] = 3      # the P4 box operator defaults to k_stiffness_march; 3 selects the k-split kernel
                     ops.append((f"{mode} {bx}x{by} lz={lz}", w.StiffnessOperator(V, p, structured=mode == "box", tuning=t)))
             if old and mode == "box":
                 for v in (0, 1, 2):

@@ -67,6 +67,9 @@ python3 "$R/tools/bench_generic_orderings.py" 2>/dev/null > "$OUT/generic_orderi
 say "f64 MFMA rate, HBM read rate, TSMM and tet timelines (diagnostic binaries built beforehand into examples/bin)"
 [ -x "$R/examples/bin/mfma_rate" ] && "$R/examples/bin/mfma_rate" > "$OUT/mfma_f64_rate.log"
 [ -x "$R/examples/bin/hbm_read_rate" ] && "$R/examples/bin/hbm_read_rate" > "$OUT/hbm_read_rate.log"
+if [ -f "$R/examples/bin/libwavehip_mstrace.so" ]; then
+  for p in 2 4 6; do P=$p python3 "$R/tools/mass_trace.py" 2>/dev/null | grep -v amdgpu.ids; done > "$OUT/mass_trace.log"
+fi
 if [ -x "$R/examples/bin/tsmm_trace" ]; then
   { echo "== 100000 x 125, layout 0"; "$R/examples/bin/tsmm_trace" 100000 125 0; echo "== 100000 x 125, layout 1"; "$R/examples/bin/tsmm_trace" 100000 125 1;
     echo "== 1000000 x 125, layout 0"; "$R/examples/bin/tsmm_trace" 1000000 125 0; } > "$OUT/tsmm_trace.log" 2>&1

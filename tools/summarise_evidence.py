@@ -207,7 +207,7 @@ def main():
                 g = sum(c["GRBM_GUI_ACTIVE"]) / len(c["GRBM_GUI_ACTIVE"])
                 L.append(f"| `{k[:60]}` | {len(c['GRBM_GUI_ACTIVE'])} | {b:.4g} | {g:.4g} | {b/(g/8*1024):.2f} |")
         L.append("")
-    for nm in ("rk4.jsonl", "generic_orderings.log", "mfma_f64_rate.log", "hbm_read_rate.log", "tsmm_trace.log", "dense_trace.log"):
+    for nm in ("rk4.jsonl", "generic_orderings.log", "mfma_f64_rate.log", "hbm_read_rate.log", "tsmm_trace.log", "dense_trace.log", "mass_trace.log", "power_ramp.log"):
         p = os.path.join(src, nm)
         if os.path.exists(p):
             shutil.copy(p, os.path.join(dst, f"{tag}_{nm}"))
