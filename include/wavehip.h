@@ -94,6 +94,14 @@ int wf_tabulate_dense(int P, double* h_table);
 int wf_reorder_dofmap(int ncells, int nd, const int32_t* h_perm,
                       const int32_t* h_in, int32_t* h_out);
 
+/* Setup-time renumbering option: a dof numbering that follows the lattice columns the marching kernels walk
+ * (work items in z-segment / column order, inside an item plane by plane, row by row), for spaces whose own
+ * numbering scatters a cell's dofs over memory.  The reference takes DOLFINx's numbering as it comes
+ * (fem::create_functionspace, demo/cpu_planar3d/main.cpp:47-52, reordered by DOLFINx's graph reordering); a
+ * caller applies h_new_of_old to its dofmap and vectors before creating operators.  Host only.
+ * h_dofmap: tensor-ordered (x fastest) [ncells][(degree+1)^3]; h_new_of_old[ndofs]. */
+int wf_lattice_numbering(int degree, int64_t ncells, int32_t ndofs, const int32_t* h_dofmap, int32_t* h_new_of_old);
+
 /* ---- a2/a13: geometry (device kernel, host in/out) -----------------------
  * common/precomputation.hpp:18-110 precompute_geometric_data (use_fabs = 1,
  * clamp = 1) and common/precompute.hpp:49-176 (use_fabs = 0, clamp = 0).

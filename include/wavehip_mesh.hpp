@@ -92,6 +92,18 @@ struct MeshSpace {
   }
 };
 
+// Setup-time renumbering option (wf_lattice_numbering): renumber the space so that its dofs follow the lattice
+// columns the marching kernels walk; returns new_of_old (vectors of the old numbering move as
+// x_new[new_of_old[d]] = x_old[d]).  DOLFINx's own numbering is local enough (first-touch: 0.222 vs 0.208 ms at
+// cfg2); a scattered one costs 2.8x and is brought back to 0.217 ms by this.
+inline std::vector<std::int32_t> renumber_lattice(MeshSpace& V)
+{
+  std::vector<std::int32_t> new_of_old((std::size_t)V.ndofs);
+  check(wf_lattice_numbering(V.degree, (std::int64_t)V.mesh->ncells(), (std::int32_t)V.ndofs, V.dofmap.data(), new_of_old.data()));
+  for (auto& d : V.dofmap) d = new_of_old[(std::size_t)d];
+  return new_of_old;
+}
+
 inline MeshSpace create_functionspace(const FileMesh& mesh, int degree)
 {
   MeshSpace V;

@@ -101,3 +101,34 @@ def test_facets_masses_and_cfl_match_numpy():
     bad = mesh_io.MeshTags(np.array([[0, 1, 2, 99]], dtype=np.int32), np.array([1], dtype=np.int32))
     with pytest.raises(ValueError):
         mesh_io.locate_facets(mesh, bad, 1)
+
+
+@pytest.mark.parametrize("p", [1, 2, 4])
+def test_lattice_numbering_is_a_permutation_with_contiguous_rows(p):
+    """wf_lattice_numbering (the setup-time renumbering option): from a uniformly random dof numbering of a box
+    it returns a permutation under which every x-row of a cell column is contiguous, consecutive rows of a
+    plane follow each other, and a mesh that does not tile still gets a valid (first-touch) permutation."""
+    import wave_fenics_amd as w
+    mesh = w.create_box((5, 4, 9))
+    V = w.create_functionspace(mesh, p)
+    rng = np.random.default_rng(p)
+    scr = rng.permutation(V.ndofs).astype(np.int32)
+    Vs = w.renumber(V, scr)
+    new = w.lattice_numbering(Vs)
+    assert sorted(new.tolist()) == list(range(V.ndofs))
+    Vn = w.renumber(Vs, new)
+    n = p + 1
+    dm = Vn.dofmap.reshape(-1, n, n, n)            # [cell][k][j][i]
+    d = np.diff(dm, axis=3)
+    assert (d == 1).mean() > 0.9                    # rows contiguous (a row may cross into a face plane numbered by the neighbour column)
+    # a cell's dofs span far less memory than under the scrambled numbering
+    span_new = (dm.reshape(len(dm), -1).max(1) - dm.reshape(len(dm), -1).min(1)).mean()
+    dms = Vs.dofmap.reshape(len(dm), -1)
+    span_old = (dms.max(1) - dms.min(1)).mean()
+    assert span_new < 0.25 * span_old
+    # non-tiling input (two cells glued with inconsistent corner dofs): still a permutation
+    bad = np.arange(2 * n ** 3, dtype=np.int32).reshape(2, -1)
+    bad[1, 0] = bad[0, 0]
+    Vb = w.FunctionSpace(mesh, p, bad, w.IndexMap(2 * n ** 3), (0, 0, 0), structured=False)
+    nb = w.lattice_numbering(Vb)
+    assert sorted(nb.tolist()) == list(range(2 * n ** 3))

@@ -383,3 +383,34 @@ def test_file_rendezvous_with_polling_rank(gpu, tmp_path):
     c = Comm.from_file(path, 0, 1)
     assert c.rccl_version() >= 20000 and not os.path.exists(path)
     c.close()
+
+
+@pytest.mark.parametrize("p", [2, 4])
+@pytest.mark.parametrize("kind", ["glued_rotated", "random_orient"])
+def test_lattice_renumbering_keeps_the_operator(gpu, oracle, kind, p):
+    """wf_lattice_numbering (setup-time renumbering option) on a re-oriented mesh whose dofs were numbered at
+    random: the renumbered space is a relabelling -- K x equals the oracle's on the original space, moved by
+    the permutation -- and runs the marching kernel."""
+    import wave_fenics_amd as w
+    from wave_fenics_amd import mesh_io
+    mesh, _ = build_mesh(kind, p)
+    V = mesh_io.create_functionspace(mesh, p)
+    om = oracle_mesh(oracle, mesh, V)
+    K = oracle.StiffnessOperator(om, p)
+    rng = np.random.default_rng(p)
+    x = rng.uniform(-1, 1, V.ndofs)
+    yref = np.zeros(V.ndofs)
+    K(x, yref)
+    scr = rng.permutation(V.ndofs).astype(np.int32)
+    Vs = w.renumber(V, scr)
+    new = w.lattice_numbering(Vs)
+    assert sorted(new.tolist()) == list(range(V.ndofs))
+    Vn = w.renumber(Vs, new)
+    both = new[scr]                                   # original index -> final index
+    xn = np.empty_like(x)
+    xn[both] = x
+    op = w.StiffnessOperator(Vn, p, {"c0": 1500.0}, structured=False, tuning={"kernel": "march"})
+    assert op.kernel == "march_idx"
+    y = dev(np.zeros(V.ndofs), gpu)
+    op(dev(xn, gpu), y)
+    assert relerr(y.cpu().numpy()[both], yref) <= TOL

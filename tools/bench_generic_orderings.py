@@ -47,10 +47,19 @@ def main():
     ft[flat[np.sort(first)]] = np.arange(V.ndofs, dtype=np.int32)
     for name, cp, dp in (("lexicographic", None, None), ("random cell order", cperm, None), ("first-touch numbering", None, ft),
                          ("first-touch + random cells", cperm, ft), ("random dof numbering", None, dperm),
-                         ("both random", cperm, dperm)):
+                         ("both random", cperm, dperm), ("both random + wf_lattice_numbering", cperm, "lattice")):
         dm = V.dofmap if cp is None else V.dofmap[cp]
         gd = mesh.geom_dofmap if cp is None else mesh.geom_dofmap[cp]
-        if dp is not None:
+        if isinstance(dp, str):
+            # the setup-time renumbering option applied to the scrambled space
+            import time as _t
+            dm = dperm[dm]
+            Vs = w.FunctionSpace(mesh, p, np.ascontiguousarray(dm), w.IndexMap(V.ndofs), V.lattice, structured=False)
+            t0 = _t.time()
+            new = w.lattice_numbering(Vs)
+            name += f" ({_t.time() - t0:.1f} s on the host)"
+            dm = new[dm]
+        elif dp is not None:
             dm = dp[dm]
         m2 = w.BoxMesh(mesh.n, mesh.x, np.ascontiguousarray(gd))
         V2 = w.FunctionSpace(m2, p, np.ascontiguousarray(dm), w.IndexMap(V.ndofs), V.lattice, structured=False)

@@ -9,7 +9,7 @@ PyTorch is used for device memory, streams and torch.distributed only.
 There is no CPU fallback: importing the operators without libwavehip raises.
 """
 from ._lib import lib, check, WavehipError  # noqa: F401
-from .box import BoxMesh, FunctionSpace, IndexMap, create_box, create_functionspace  # noqa: F401
+from .box import BoxMesh, FunctionSpace, IndexMap, create_box, create_functionspace, lattice_numbering, renumber  # noqa: F401
 from .operators import (  # noqa: F401
     StiffnessOperator, MassOperator, SpectralMassOperator, MassOperatorLumped,
     gather, scatter, transform1, tsmm, tabulate_gll, tabulate_dense, precompute_geometric_data,

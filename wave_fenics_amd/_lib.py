@@ -110,6 +110,7 @@ SIGNATURES = {
     "wf_tabulate_1d": (c_int, [c_int, c_int, c_int, _dp, c_int, _dp]),
     "wf_geometry_hex_rule": (c_int, [c_int, c_int, _dp, _ip, c_int, _dp, _dp, c_int, c_int, _dp, _dp]),
     "wf_reorder_dofmap": (c_int, [c_int, c_int, _ip, _ip, _ip]),
+    "wf_lattice_numbering": (c_int, [c_int, ctypes.c_int64, ctypes.c_int32, _ip, _ip]),
     "wf_geometry_hex": (c_int, [c_int, c_int, c_int, _dp, _ip, c_int, c_int, _dp, _dp]),
     "wf_op_create": (c_int, [POINTER(OpDesc), POINTER(c_void_p)]),
     "wf_op_create_box": (c_int, [c_int, c_int, c_int, c_int, c_int, _dp, c_double, c_int, POINTER(c_void_p)]),

@@ -52,6 +52,25 @@ class FunctionSpace:
         return self.index_map.size_local + self.index_map.num_ghosts
 
 
+def lattice_numbering(V: "FunctionSpace") -> np.ndarray:
+    """Setup-time renumbering option (wf_lattice_numbering): new index of every dof of V in a numbering that follows
+    the lattice columns the marching kernels walk.  For spaces whose own numbering scatters a cell's dofs over
+    memory (a uniformly random numbering costs 2.8x in the stiffness apply)."""
+    from ._lib import check, lib
+    dm = np.ascontiguousarray(V.dofmap, dtype=np.int32)
+    out = np.empty(V.ndofs, dtype=np.int32)
+    import ctypes
+    ip = ctypes.POINTER(ctypes.c_int32)
+    check(lib().wf_lattice_numbering(V.degree, dm.shape[0], V.ndofs, dm.ctypes.data_as(ip), out.ctypes.data_as(ip)))
+    return out
+
+
+def renumber(V: "FunctionSpace", new_of_old: np.ndarray) -> "FunctionSpace":
+    """The same space with dof d renamed new_of_old[d]; vectors move as x_new[new_of_old] = x_old."""
+    return FunctionSpace(V.mesh, V.degree, np.ascontiguousarray(new_of_old[V.dofmap].astype(np.int32)), V.index_map, V.lattice,
+                         structured=False)
+
+
 def create_box(n, lo=(0.0, 0.0, 0.0), hi=(1.0, 1.0, 1.0), perturb: float = 0.0, seed: int = 42) -> BoxMesh:
     """mesh::create_box(comm, {lo, hi}, {nx, ny, nz}, hexahedron).  perturb > 0
     displaces interior vertices by perturb*h*U(-1,1) (numpy default_rng(seed))."""

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <array>
 #include <cstdint>
 #include <cstdio>
 #include <string>
@@ -104,6 +105,7 @@ struct MarchPlan {
   std::vector<int32_t> item_base;       // [nitems] smallest dof of the item
   std::vector<int32_t> item_pattern;    // [nitems]
   std::vector<int32_t> item_layers;     // [nitems] non-empty layers (<= lz)
+  std::vector<std::array<int32_t, 4>> item_key;   // [nitems] (lattice component, column x, column y, z segment)
   std::vector<int32_t> pat_off;         // [npatterns][tile_size] dof - base per tile position, -1 = uncovered
 };
 struct MarchPlanDev {
