@@ -190,8 +190,8 @@ def test_mass_operators_on_reoriented_meshes(gpu, oracle, kind, p):
 
 
 def test_thin_column_mesh_keeps_the_batch_kernel(gpu, oracle):
-    """A mesh one cell wide fills a tenth of the slots of its lattice columns (P4: 5 x 2 cells per
-    layer): the marching kernel would read ten times the geometry -- the plan is dropped on its
+    """A mesh one cell wide fills a fifth of the slots of its lattice columns (P4: 5 x 1 cells per
+    layer): the marching kernel would read five times the geometry -- the plan is dropped on its
     fill factor (and adopted when forced, with the same answer)."""
     import wave_fenics_amd as w
     p, n = 4, (1, 1, 24)
@@ -205,7 +205,7 @@ def test_thin_column_mesh_keeps_the_batch_kernel(gpu, oracle):
     op = w.StiffnessOperator(V, p, structured=False)
     assert op.kernel == "batch_unique"
     opm = w.StiffnessOperator(V, p, structured=False, tuning={"kernel": "march"})
-    assert opm.kernel == "march_idx" and opm.info.plan_fill < 0.2
+    assert opm.kernel == "march_idx" and opm.info.plan_fill <= 0.2
     for o in (op, opm):
         y = dev(np.zeros(om.ndofs), gpu)
         o(dev(x, gpu), y)

@@ -23,6 +23,8 @@
 // y accumulated, coefficient -c0^2 (operators.hpp:114-115).
 #include <cstdlib>
 
+#include <type_traits>
+
 #include "stiffness_core.h"
 
 namespace wf {
@@ -38,6 +40,9 @@ namespace wf {
 //    instead of the round-robin order: 0.247 ms.
 // Diagnostic build (tools/march_trace.sh): per-wave timestamps of the phases of the first layers of
 // the first 512 workgroups, 100 MHz constant clock.
+#ifndef WF_MARCH_BRANCHLESS_ROTATE
+#define WF_MARCH_BRANCHLESS_ROTATE 1
+#endif
 #ifndef WF_MARCH_TILE_ADD
 #define WF_MARCH_TILE_ADD 1
 #endif
@@ -68,7 +73,9 @@ __global__ __launch_bounds__(256, 2) void k_stiffness_march(int nx, int ny, int 
   constexpr int NCP = (TP + 255) / 256;             // positions of one plane per thread
   static_assert(NT <= 256, "column does not fit a 256-thread workgroup");
 
-  __shared__ __attribute__((aligned(16))) double Ux[(P + 1) * TP];   // x planes of the layer
+  // x planes of the layer + a dump row: threads whose last position lies past the tile store there, so that the
+  // stores that consume the prefetched x registers sit in straight-line code (see (c))
+  __shared__ __attribute__((aligned(16))) double Ux[(P + 1) * TP + (WF_MARCH_BRANCHLESS_ROTATE ? 256 : 0)];
 #if WF_MARCH_TILE_ADD
   // results of the layer's cells, summed where they share a face (ds_add_f64): planes 0..P-1 of the tile.  The
   // flush of a position is then one LDS read (+ the zero for the next layer) and one global atomic; as a gather
@@ -171,8 +178,13 @@ __global__ __launch_bounds__(256, 2) void k_stiffness_march(int nx, int ny, int 
   // swap roles from layer to layer (the loop below is unrolled by two): a copy gcur = gnext is
   // placed by the compiler at the loop's back edge, behind the flush, and then waits for the
   // prefetch AND the atomics in front of it.
-  auto layer = [&](double2 (&gcur)[n][3], double2 (&gnext)[n][3], int kz) {
-    const bool has_next = kz + 1 < z1;
+  // `has_next` is a compile-time property of the layer body (two copies, chosen by one uniform branch per layer):
+  // with `if (has_next)` around each prefetch instalment the compiler merges, at every join, the wait-count state
+  // of the path that issued the geometry loads with the one that did not -- in which the x loads are the YOUNGEST
+  // pending loads -- and the rotate then waited with vmcnt(2)/(1)/(0), i.e. for the geometry instalments issued
+  // after the x loads too, instead of vmcnt(11)/(10)/(9).
+  auto layer = [&](auto hn_tag, double2 (&gcur)[n][3], double2 (&gnext)[n][3], int kz) {
+    const bool has_next = hn_tag;   // a compile-time constant for the specialised copies (P >= 4)
     const size_t base = plane * (size_t)(P * kz);   // first lattice plane of this layer
     WF_MTR(0);
 
@@ -231,6 +243,22 @@ __global__ __launch_bounds__(256, 2) void k_stiffness_march(int nx, int ny, int 
     // atomics share vmcnt on gfx9 and the compiler waits for vmcnt(0) once both kinds are pending:
     // placed after the flush, every layer waited for the round trip of its own atomics.
     if (has_next) {
+#if WF_MARCH_BRANCHLESS_ROTATE
+      // No per-lane branches between the prefetch and its consumers: behind an exec-masked branch the compiler's
+      // wait-count bookkeeping fell back to vmcnt(0), i.e. the rotate waited for the geometry instalments issued
+      // AFTER the x loads as well (ISA: s_waitcnt vmcnt(1) / (2) / (0) in front of the three stores).  Only a
+      // thread's last position can lie outside the tile; it is stored to the dump row instead.
+#pragma unroll
+      for (int m = 0; m < NCP; ++m) {
+        const int pos = t + 256 * m;
+        Ux[(256 * (m + 1) <= TP || pos < TP) ? pos : (P + 1) * TP + t] = xcp[m];
+      }
+#pragma unroll
+      for (int m = 0; m < NPOS; ++m) {
+        const int pos = t + 256 * m;
+        Ux[(256 * (m + 1) <= P * TP || pos < P * TP) ? TP + pos : (P + 1) * TP + t] = poff[m] >= 0 ? xn[m] : 0.0;
+      }
+#else
 #pragma unroll
       for (int m = 0; m < NCP; ++m) {
         const int pos = t + 256 * m;
@@ -241,6 +269,7 @@ __global__ __launch_bounds__(256, 2) void k_stiffness_march(int nx, int ny, int 
         const int pos = t + 256 * m;
         if (pos < P * TP) Ux[TP + pos] = poff[m] >= 0 ? xn[m] : 0.0;
       }
+#endif
     }
     __builtin_amdgcn_sched_barrier(0);   // keep the LDS writes (and the wait for xn) above the atomics
     if (has_next) load_g(gnext, kzn, G2, n);
@@ -283,9 +312,28 @@ __global__ __launch_bounds__(256, 2) void k_stiffness_march(int nx, int ny, int 
 
     __syncthreads();
   };
+  using HasNext = std::integral_constant<bool, true>;
+  using IsLast = std::integral_constant<bool, false>;
+  struct RunTime {
+    bool v;
+    __device__ operator bool() const { return v; }
+  };
+  // P <= 3 issues the whole prefetch in one burst at the top of the layer and measured 6 % SLOWER with the two
+  // copies (P2 0.3125 -> 0.3325 ms; P3 unchanged; P4 0.2017 -> 0.1954 ms): one body with a run-time flag there.
+  constexpr bool kTwoCopies = P >= 4;
   for (int kz = z0; kz < z1; kz += 2) {
-    layer(gA, gB, kz);
-    if (kz + 1 < z1) layer(gB, gA, kz + 1);
+    if constexpr (!kTwoCopies) {
+      layer(RunTime{kz + 1 < z1}, gA, gB, kz);
+      if (kz + 1 < z1) layer(RunTime{kz + 2 < z1}, gB, gA, kz + 1);
+    } else if (kz + 1 < z1) {
+      layer(HasNext{}, gA, gB, kz);
+      if (kz + 2 < z1)
+        layer(HasNext{}, gB, gA, kz + 1);
+      else
+        layer(IsLast{}, gB, gA, kz + 1);
+    } else {
+      layer(IsLast{}, gA, gB, kz);
+    }
   }
 
   // ---- epilogue: the last (carried) plane ------------------------------------

@@ -267,7 +267,8 @@ static int launch_t(const MarchPlanDev& pd, const double* d_G6blk, const double*
 }
 
 // the stiffness operator runs the k-split kernel (stiffness_march_ks.hip) at P >= 5
-static bool march_idx_uses_ks(int P) { return P >= 5; }
+// P >= 4 runs the k-split kernel (cfg2, any dofmap: k_march_idx<4,5,2> 0.208 ms, k_march_ks<4,5,1,true> 0.197 ms)
+static bool march_idx_uses_ks(int P) { return P >= 4; }
 
 // the cross-sections with BX * BY == floor(256 / n^2) cells (geometry batch layout)
 void march_idx_shape(int kind, int P, int* bx, int* by)

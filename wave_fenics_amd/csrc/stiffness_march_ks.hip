@@ -23,6 +23,8 @@
 // IDX = true : any dofmap, addresses from the work item's index table staged in LDS
 //              (k_march_idx's interface, plan of generic_plan.cpp).
 // HBM-bound; algorithmic bytes ncells (48 nq + 4 nd) + 16 ndofs.
+#include <type_traits>
+
 #include "stiffness_core.h"
 
 namespace wf {
@@ -312,8 +314,13 @@ __device__ __forceinline__ void ks_march(const KSArgs& a, const DMat& dm, double
 
   // One layer.  b = l & 1 selects the LDS buffers; `gcur` holds the layer's geometry, `gnext`
   // receives the next layer's (second instalment after barrier A).
-  auto layer = [&](double2 (&gcur)[KH][3], double2 (&gnext)[KH][3], int l, int b) {
-    const bool has_next = l + 1 < nl, has_next2 = l + 2 < nl;
+  // `has_next` / `has_next2` are compile-time properties of the layer body (three copies, chosen by uniform
+  // branches in the loop below): with `if (has_next)` around each prefetch instalment the compiler merges, at every
+  // join, the wait-count state of the path that issued the geometry loads with the one that did not -- where the x
+  // loads are the youngest pending loads -- and the consumers of the x registers in (c) then wait for the geometry
+  // issued behind them too (stiffness_march.hip: vmcnt(2)/(1)/(0) instead of (11)/(10)/(9), P4 0.2017 -> 0.1954 ms).
+  auto layer = [&](auto hn_tag, auto hn2_tag, double2 (&gcur)[KH][3], double2 (&gnext)[KH][3], int l, int b) {
+    const bool has_next = hn_tag, has_next2 = hn2_tag;   // compile-time constants in the specialised copies
     const double* Ub = Ux + b * (P + 1) * TP;
     double* Un = Ux + (b ^ 1) * (P + 1) * TP;
     double* Tb = O + b * (P * TP);
@@ -381,9 +388,29 @@ __device__ __forceinline__ void ks_march(const KSArgs& a, const DMat& dm, double
     // (e) flush: runs beside the next layer's phase 1 (no barrier in between)
     if (FS == 0) flush(Tb, l, 0, NPOS);
   };
+  using Yes = std::integral_constant<bool, true>;
+  using No = std::integral_constant<bool, false>;
+  struct RunTime {
+    bool v;
+    __device__ operator bool() const { return v; }
+  };
+  // Measured per cross-section (tools/bench_shapes.py, two libraries side by side): the copies help the workgroups
+  // that request LATE (P5 3x1 0.205 -> 0.195 ms, P6 2x1 0.216 -> 0.194, P6 2x1 indexed 0.230 -> 0.205) and hurt the
+  // 512-thread ones that request EARLY (P4 5x2 0.205 -> 0.24, P5 7x1 0.219 -> 0.233, P6 5x1 0.213 -> 0.238, P7 2x2
+  // 0.171 -> 0.184), which keep one body with run-time flags.
+  auto layer_any = [&](double2 (&gcur)[KH][3], double2 (&gnext)[KH][3], int l, int b) {
+    if constexpr (EARLY)
+      layer(RunTime{l + 1 < nl}, RunTime{l + 2 < nl}, gcur, gnext, l, b);
+    else if (l + 2 < nl)
+      layer(Yes{}, Yes{}, gcur, gnext, l, b);
+    else if (l + 1 < nl)
+      layer(Yes{}, No{}, gcur, gnext, l, b);
+    else
+      layer(No{}, No{}, gcur, gnext, l, b);
+  };
   for (int l = 0; l < nl; l += 2) {
-    layer(gA, gB, l, 0);
-    if (l + 1 < nl) layer(gB, gA, l + 1, 1);
+    layer_any(gA, gB, l, 0);
+    if (l + 1 < nl) layer_any(gB, gA, l + 1, 1);
   }
 
   // ---- epilogue: the last layer's tile (unless flushed already) and the last (carried) plane --------
@@ -462,7 +489,7 @@ static int launch_ks_t(const KSArgs& a, const DMat& dm, int nwg, size_t lds, hip
 #define WF_KS_SHAPES(X)                                                                   \
   X(4, 5, 1) X(4, 5, 2)                                                                   \
   X(5, 3, 1) X(5, 7, 1) X(5, 2, 1)                                                        \
-  X(6, 1, 1) X(6, 2, 1) X(6, 5, 1)                                                        \
+  X(6, 2, 1) X(6, 1, 1) X(6, 5, 1)                                                        \
   X(7, 2, 1) X(7, 2, 2) X(7, 1, 1)
 
 bool march_ks_shape(int P, int* bx, int* by)
