@@ -25,6 +25,8 @@
 // tools/mass_trace.sh/.py: per-wave phase timeline.  P6 before these four changes (private per-cell results gathered
 // by the flush, whole table staged in LDS: lz = 4): layer 5.0 us = prefetch issue 1.0 + passes 1.4 + x -> LDS 0.5 +
 // flush 1.8; now about 3.2 us.  HBM-bound by its bytes (8 B of det J w per point + x + y), latency-bound in practice.
+#include <type_traits>
+
 #include "stiffness_core.h"
 
 namespace wf {
@@ -52,7 +54,8 @@ struct MassLayout {
   static constexpr int oO = oUx + 2 * (P + 1) * TP;       // [2][P TP] result tile of a layer, cells combined
   static constexpr int oCy = oO + 2 * P * TP;             // [2][CB n2]
   static constexpr int oA = oCy + 2 * CB * n2;            // [CB nd] wave-private scratch of a cell (the passes work in place)
-  static constexpr int ndoubles = ((oA + CB * nd + 1) / 2) * 2;
+  static constexpr int oDump = oA + CB * nd;               // [WG] where a thread's out-of-tile last position is stored
+  static constexpr int ndoubles = ((oDump + 64 * ((CB + CW - 1) / CW) + 1) / 2) * 2;
   // ring of index-table planes behind the doubles: at the time layer l stores the planes of layer l + 2
   // (<= P l + 3 P) the flush of layer l - 1 may still read plane P (l - 1): 4 P + 1 planes are live
   static constexpr int RP = 4 * P + 1, RPT = RP * TP;
@@ -62,9 +65,9 @@ struct MassLayout {
 size_t mass_march_lds_bytes(int P, int BX, int BY, int lz)
 {
   const int n = P + 1, n2 = n * n, nd = n * n2, CB = BX * BY, TP = (P * BX + 1) * (P * BY + 1);
-  const size_t d = (size_t)2 * (P + 1) * TP + (size_t)2 * P * TP + (size_t)2 * CB * n2 + (size_t)CB * nd + 2;
+  const size_t d = (size_t)2 * (P + 1) * TP + (size_t)2 * P * TP + (size_t)2 * CB * n2 + (size_t)CB * nd + 64 * (size_t)((CB + (64 / n2) - 1) / (64 / n2)) + 2;
   (void)lz;   // the index table streams through a ring of 4 P + 1 planes: the footprint does not depend on the segment length
-  return d * sizeof(double) + (size_t)(4 * P + 1) * TP * sizeof(int32_t);
+  return d * sizeof(double) + ((size_t)(4 * P + 1) * TP + 64 * (size_t)((CB + (64 / n2) - 1) / (64 / n2))) * sizeof(int32_t);
 }
 
 struct MassArgs {
@@ -229,8 +232,13 @@ __global__ __launch_bounds__((MassLayout<P, BX, BY>::WG), 2) void k_mass_march(M
     }
   };
 
-  auto layer = [&](double (&dcur)[n], double (&dnext)[n], int l, int b) {
-    const bool has_next = l + 1 < nl;
+  // `has_next` (l + 1 < nl) and `has_next2` (l + 2 < nl) are compile-time constants of the layer body (three copies
+  // chosen by uniform branches below): a uniform `if (has_next)` around the det J prefetch makes the compiler merge,
+  // at the join, the wait-count state of the path without those loads -- in which the x / table loads are the
+  // youngest -- and (c) then waited with vmcnt(0) for the det J stream of the NEXT layer (ISA before this change).
+  // The stores of (c) sit in straight-line code: a thread's out-of-tile last position goes to a dump slot.
+  auto layer = [&](auto hn_tag, auto hn2_tag, double (&dcur)[n], double (&dnext)[n], int l, int b) {
+    constexpr bool has_next = decltype(hn_tag)::value, has_next2 = decltype(hn2_tag)::value;
     const double* Ub = Ux + b * (P + 1) * TP;
     double* Un = Ux + (b ^ 1) * (P + 1) * TP;
     double* Tb = O + b * (P * TP);
@@ -324,21 +332,28 @@ __global__ __launch_bounds__((MassLayout<P, BX, BY>::WG), 2) void k_mass_march(M
     WF_MSTR(6);
     // (c) x planes of the next layer -> the other buffer (the consumer of xn)
     if (has_next) {
+      double* dumpd = ms_smem + L::oDump + t;
+      int32_t* dumpi = sIdx + RPT + t;
 #pragma unroll
       for (int m = 0; m < NCP; ++m) {
         const int pos = t + WG * m;
-        if (pos < TP) Un[pos] = Ub[P * TP + pos];
+        const bool in = WG * (m + 1) <= TP || pos < TP;
+        const double v = Ub[P * TP + (in ? pos : 0)];
+        *(in ? Un + pos : dumpd) = v;
       }
 #pragma unroll
       for (int m = 0; m < NPOS; ++m) {
         const int pos = t + WG * m;
-        if (pos < P * TP) Un[TP + pos] = sIdx[ring(rb_x, pos)] >= 0 ? xn[m] : 0.0;
+        const bool in = WG * (m + 1) <= P * TP || pos < P * TP;
+        const int32_t off = sIdx[ring(rb_x, in ? pos : 0)];
+        *(in ? Un + TP + pos : dumpd) = off >= 0 ? xn[m] : 0.0;
       }
-      if (l + 2 < nl) {
+      if (has_next2) {
 #pragma unroll
         for (int m = 0; m < NPOS; ++m) {
           const int pos = t + WG * m;
-          if (pos < P * TP) sIdx[ring(rb_in, pos)] = tn[m];
+          const bool in = WG * (m + 1) <= P * TP || pos < P * TP;
+          *(in ? sIdx + ring(rb_in, pos) : dumpi) = tn[m];
         }
       }
     }
@@ -350,9 +365,19 @@ __global__ __launch_bounds__((MassLayout<P, BX, BY>::WG), 2) void k_mass_march(M
     __syncthreads();   // the one workgroup barrier of the layer
     WF_MSTR(8);
   };
+  using Yes = std::integral_constant<bool, true>;
+  using No = std::integral_constant<bool, false>;
+  auto layer_any = [&](double (&dcur)[n], double (&dnext)[n], int l, int b) {
+    if (l + 2 < nl)
+      layer(Yes{}, Yes{}, dcur, dnext, l, b);
+    else if (l + 1 < nl)
+      layer(Yes{}, No{}, dcur, dnext, l, b);
+    else
+      layer(No{}, No{}, dcur, dnext, l, b);
+  };
   for (int l = 0; l < nl; l += 2) {
-    layer(dA, dB, l, 0);
-    if (l + 1 < nl) layer(dB, dA, l + 1, 1);
+    layer_any(dA, dB, l, 0);
+    if (l + 1 < nl) layer_any(dB, dA, l + 1, 1);
   }
 
   // ---- epilogue: the last layer's tile and the last (carried) plane ---------------------------------------------------
