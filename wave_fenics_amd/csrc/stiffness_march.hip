@@ -314,17 +314,13 @@ __global__ __launch_bounds__(256, 2) void k_stiffness_march(int nx, int ny, int 
   };
   using HasNext = std::integral_constant<bool, true>;
   using IsLast = std::integral_constant<bool, false>;
-  struct RunTime {
-    bool v;
-    __device__ operator bool() const { return v; }
-  };
   // P <= 3 issues the whole prefetch in one burst at the top of the layer and measured 6 % SLOWER with the two
   // copies (P2 0.3125 -> 0.3325 ms; P3 unchanged; P4 0.2017 -> 0.1954 ms): one body with a run-time flag there.
   constexpr bool kTwoCopies = P >= 4;
   for (int kz = z0; kz < z1; kz += 2) {
     if constexpr (!kTwoCopies) {
-      layer(RunTime{kz + 1 < z1}, gA, gB, kz);
-      if (kz + 1 < z1) layer(RunTime{kz + 2 < z1}, gB, gA, kz + 1);
+      layer(kz + 1 < z1, gA, gB, kz);   // (plain bools: a wrapper struct with operator bool compiled to 6 % slower code)
+      if (kz + 1 < z1) layer(kz + 2 < z1, gB, gA, kz + 1);
     } else if (kz + 1 < z1) {
       layer(HasNext{}, gA, gB, kz);
       if (kz + 2 < z1)

@@ -390,17 +390,13 @@ __device__ __forceinline__ void ks_march(const KSArgs& a, const DMat& dm, double
   };
   using Yes = std::integral_constant<bool, true>;
   using No = std::integral_constant<bool, false>;
-  struct RunTime {
-    bool v;
-    __device__ operator bool() const { return v; }
-  };
   // Measured per cross-section (tools/bench_shapes.py, two libraries side by side): the copies help the workgroups
   // that request LATE (P5 3x1 0.205 -> 0.195 ms, P6 2x1 0.216 -> 0.194, P6 2x1 indexed 0.230 -> 0.205) and hurt the
   // 512-thread ones that request EARLY (P4 5x2 0.205 -> 0.24, P5 7x1 0.219 -> 0.233, P6 5x1 0.213 -> 0.238, P7 2x2
   // 0.171 -> 0.184), which keep one body with run-time flags.
   auto layer_any = [&](double2 (&gcur)[KH][3], double2 (&gnext)[KH][3], int l, int b) {
-    if constexpr (EARLY)
-      layer(RunTime{l + 1 < nl}, RunTime{l + 2 < nl}, gcur, gnext, l, b);
+    if constexpr (EARLY || (P == 7 && BX * BY > 1))   // (P7 2x1: 0.165 ms with one body, 0.167 with the copies)
+      layer(l + 1 < nl, l + 2 < nl, gcur, gnext, l, b);   // (plain bools: a wrapper struct with operator bool compiled to slower code)
     else if (l + 2 < nl)
       layer(Yes{}, Yes{}, gcur, gnext, l, b);
     else if (l + 1 < nl)
