@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""Diagnostic: phase timeline of the indexed marching kernel (k_march_idx) for the dense mass or the
-generic stiffness operator, from a library built with -DWF_IDX_TRACE
+"""Diagnostic: phase timeline of the indexed marching kernel of the low degrees (k_march_idx, P <= 3; P >= 4 runs
+the k-split kernel, the dense mass has tools/mass_trace.py), from a library built with -DWF_IDX_TRACE
 (examples/bin/libwavehip_itrace.so; see tools/march_trace.sh for the recipe).
-usage: idx_trace.py mass|stiffness [P]"""
+usage: idx_trace.py [P]"""
 import ctypes
 import os
 import sys
@@ -21,27 +21,15 @@ ITERS, SLOTS = 12, 6
 
 
 def main():
-    kind = sys.argv[1] if len(sys.argv) > 1 else "mass"
-    p = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+    kind = "stiffness"
+    p = int(sys.argv[1]) if len(sys.argv) > 1 else 3
     n = 216 // p
     dev = torch.device("cuda", 0)
     V = w.create_functionspace(w.create_box(n), p, build_dofmap=True)
     V.structured = False
-    if kind == "mass":
-        # square 1-D table (p + 1 Gauss points, equispaced nodes): the marching path of the dense mass operator
-        gx, gw = np.polynomial.legendre.leggauss(p + 1)
-        qp, qw = 0.5 * (gx + 1), 0.5 * gw
-        nodes = np.linspace(0, 1, p + 1)
-        phi1 = np.array([[np.prod([(q - nodes[m]) / (nodes[a] - nodes[m]) for m in range(p + 1) if m != a]) for a in range(p + 1)] for q in qp])
-        W3 = np.einsum("k,j,i->kji", qw, qw, qw).reshape(-1)
-        mesh = V.mesh if hasattr(V, "mesh") else None
-        ncells = n ** 3
-        detq = np.tile(W3 / ncells, (ncells, 1))
-        op = w.MassOperator(V, p, phi1, detq)
-        names = ["(a) issue prefetch", "(b) mass_column (3 barriers)", "O write + barrier", "flush (atomics)", "rotate (waits for prefetch)", "end barrier"]
-    else:
-        op = w.StiffnessOperator(V, p, {"c0": 1500.0})
-        names = ["(a) issue prefetch", "(b) element kernels", "O write + barrier", "rotate", "flush (atomics)", "end barrier"]
+    op = w.StiffnessOperator(V, p, {"c0": 1500.0})
+    assert op.kernel == "march_idx" and p <= 3
+    names = ["(a) issue prefetch", "(b) element kernels", "tile add + barrier", "rotate", "flush (atomics)", "end barrier"]
     x = torch.rand(V.ndofs, dtype=torch.float64, device=dev)
     y = torch.zeros(V.ndofs, dtype=torch.float64, device=dev)
     for _ in range(3):

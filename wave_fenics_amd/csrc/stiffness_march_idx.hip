@@ -125,15 +125,16 @@ __global__ __launch_bounds__(256, 2) void k_march_idx(int lz, int tile_size, con
     const bool has_next = l + 1 < nl;
     WF_ITR(0);
     // (a) next layer's x planes and geometry: in flight during this layer's arithmetic
+    // (unconditional loads on clamped addresses -- dead entries and positions past the tile read the item's first
+    // dof, the last layer its own planes again: a guard around a load is a branch, and behind it the compiler waits
+    // for every memory operation still pending; what is live is decided where the registers are consumed)
     double xn[NPOS];
+    const int ln = has_next ? l + 1 : l;
 #pragma unroll
     for (int m = 0; m < NPOS; ++m) {
       const int pos = t + 256 * m;
-      xn[m] = 0.0;
-      if (has_next && pos < P * TP) {
-        const int32_t off = sIdx[(P * (l + 1) + 1) * TP + pos];
-        if (off >= 0) xn[m] = x[gbase + off];
-      }
+      const int32_t off = pos < P * TP ? sIdx[(P * ln + 1) * TP + pos] : -1;
+      xn[m] = x[gbase + (off >= 0 ? off : 0)];
     }
     if (has_next && active) load_g(gnext, l + 1, 0, G1);
 
@@ -178,7 +179,7 @@ __global__ __launch_bounds__(256, 2) void k_march_idx(int lz, int tile_size, con
 #pragma unroll
       for (int m = 0; m < NPOS; ++m) {
         const int pos = t + 256 * m;
-        if (pos < P * TP) Ux[TP + pos] = xn[m];
+        if (pos < P * TP) Ux[TP + pos] = sIdx[(P * ln + 1) * TP + pos] >= 0 ? xn[m] : 0.0;
       }
     }
     };
