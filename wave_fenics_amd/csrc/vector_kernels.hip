@@ -82,9 +82,12 @@ __global__ void k_div(int64_t n, const double* b, const double* m, double* out)
 // RK4 loop / the bench step they are streamed once per pass, while b (= y of the stiffness apply) and the
 // apply's x are what the next stiffness apply touches again and should keep the Infinity Cache
 // (cfg2: 4 x 82 MB of vectors do not fit its 256 MB, x + y do).
-__global__ void k_div2(int64_t npairs, const double* __restrict__ b, const double* __restrict__ m, double* __restrict__ out)
+// `tail` (0 or 1): the odd last entry, done by the first thread of the last block in the same launch (as its own
+// launch it cost 4 us of the 44 us the mass-inverse takes in the bench step).
+__global__ void k_div2(int64_t npairs, int tail, const double* __restrict__ b, const double* __restrict__ m, double* __restrict__ out)
 {
   typedef double d2v __attribute__((ext_vector_type(2)));
+  if (tail && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) out[2 * npairs] = b[2 * npairs] / m[2 * npairs];
   for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < npairs; g += (int64_t)gridDim.x * blockDim.x) {
     const d2v bb = reinterpret_cast<const d2v*>(b)[g];
     const d2v mm = __builtin_nontemporal_load(reinterpret_cast<const d2v*>(m) + g);
@@ -100,9 +103,10 @@ __global__ void k_mult_add(int64_t n, const double* __restrict__ m, const double
     y[g] += m[g] * x[g];
 }
 // y += m .* x with 16-byte accesses, the diagonal streamed past the caches
-__global__ void k_mult_add2(int64_t npairs, const double* __restrict__ m, const double* __restrict__ x, double* __restrict__ y)
+__global__ void k_mult_add2(int64_t npairs, int tail, const double* __restrict__ m, const double* __restrict__ x, double* __restrict__ y)
 {
   typedef double d2v __attribute__((ext_vector_type(2)));
+  if (tail && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) y[2 * npairs] += m[2 * npairs] * x[2 * npairs];
   for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < npairs; g += (int64_t)gridDim.x * blockDim.x) {
     const d2v mm = __builtin_nontemporal_load(reinterpret_cast<const d2v*>(m) + g);
     const d2v xx = reinterpret_cast<const d2v*>(x)[g];
@@ -358,10 +362,10 @@ int wf_pointwise_div(int64_t n, const double* d_b, const double* d_m, double* d_
   const bool vec = ((reinterpret_cast<uintptr_t>(d_b) | reinterpret_cast<uintptr_t>(d_m) | reinterpret_cast<uintptr_t>(d_out)) & 15) == 0
                    && d_out != d_b && d_out != d_m;
   const int64_t nv = vec ? n / 2 : 0;
-  if (nv) hipLaunchKernelGGL(k_div2, dim3(capped_grid(nv, 256)), dim3(256), 0, (hipStream_t)stream, nv, d_b, d_m, d_out);
-  if (n > 2 * nv)
-    hipLaunchKernelGGL(k_div, dim3(capped_grid(n - 2 * nv, 256)), dim3(256), 0, (hipStream_t)stream, n - 2 * nv, d_b + 2 * nv,
-                       d_m + 2 * nv, d_out + 2 * nv);
+  if (nv)
+    hipLaunchKernelGGL(k_div2, dim3(capped_grid(nv, 256)), dim3(256), 0, (hipStream_t)stream, nv, (int)(n - 2 * nv), d_b, d_m, d_out);
+  else
+    hipLaunchKernelGGL(k_div, dim3(capped_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, n, d_b, d_m, d_out);
   WF_LAUNCH_CHECK();
   return WF_OK;
 }
@@ -371,10 +375,10 @@ int wf_pointwise_mult_add(int64_t n, const double* d_m, const double* d_x, doubl
   const bool vec = ((reinterpret_cast<uintptr_t>(d_m) | reinterpret_cast<uintptr_t>(d_x) | reinterpret_cast<uintptr_t>(d_y)) & 15) == 0
                    && d_y != d_x && d_y != d_m;
   const int64_t nv = vec ? n / 2 : 0;
-  if (nv) hipLaunchKernelGGL(k_mult_add2, dim3(capped_grid(nv, 256)), dim3(256), 0, (hipStream_t)stream, nv, d_m, d_x, d_y);
-  if (n > 2 * nv)
-    hipLaunchKernelGGL(k_mult_add, dim3(capped_grid(n - 2 * nv, 256)), dim3(256), 0, (hipStream_t)stream, n - 2 * nv, d_m + 2 * nv,
-                       d_x + 2 * nv, d_y + 2 * nv);
+  if (nv)
+    hipLaunchKernelGGL(k_mult_add2, dim3(capped_grid(nv, 256)), dim3(256), 0, (hipStream_t)stream, nv, (int)(n - 2 * nv), d_m, d_x, d_y);
+  else
+    hipLaunchKernelGGL(k_mult_add, dim3(capped_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, n, d_m, d_x, d_y);
   WF_LAUNCH_CHECK();
   return WF_OK;
 }
