@@ -140,7 +140,7 @@ def main():
         parallelism = "single"
     else:
         from wave_fenics_amd.distributed import create_distributed_box, VectorUpdater
-        part = create_distributed_box(n, p, world, rank, periodic=periodic)
+        part = create_distributed_box(n, p, world, rank, periodic=periodic, build_dofmap=args.generic)
         mesh, V = part.mesh, part.V
         V.structured = not args.generic
         # ghost exchange: the C ABI's RCCL updater (grouped ncclSend/ncclRecv per neighbour);
@@ -199,7 +199,10 @@ def main():
     split = False
     if updater is not None:
         # cells that read no ghost value run while the halo of x is in flight
-        split = K.set_ghost_faces(*[bool(v) for v in part.owned_lo])
+        if args.generic:
+            split = K.set_ghost_dofs(updater.h_ghost_pos)      # any dofmap: work items whose dof tile holds a ghost position
+        else:
+            split = K.set_ghost_faces(*[bool(v) for v in part.owned_lo])
     from wave_fenics_amd.distributed import overlapped_apply
     if rank == 0 and updater is not None:
         print(f"# ghost exchange: {updater.transport}, overlap split: {split}", file=sys.stderr, flush=True)

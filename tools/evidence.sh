@@ -20,6 +20,7 @@ python3 "$R/bench.py" > "$OUT/bench_line.json" 2> "$OUT/bench_line.err"
 python3 "$R/bench.py" --generic --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/bench_generic.json"
 python3 "$R/bench.py" --no-cpu-baseline --periodic x 2>/dev/null | tail -1 > "$OUT/bench_periodic_x.json"
 python3 "$R/bench.py" --no-cpu-baseline --periodic xyz 2>/dev/null | tail -1 > "$OUT/bench_periodic_xyz.json"
+python3 "$R/bench.py" --no-cpu-baseline --generic --periodic xyz 2>/dev/null | tail -1 > "$OUT/bench_generic_periodic_xyz.json"
 say "kernel trace of bench.py (box and generic)"
 prof kt_box "$R/bench.py" --steps 20 --warmup 3 --no-cpu-baseline
 prof kt_generic "$R/bench.py" --steps 20 --warmup 3 --no-cpu-baseline --generic

@@ -81,7 +81,7 @@ def main():
          f"source: `tools/evidence.sh {tag}` on one MI355X (gfx950, ROCm 7.2); summarised by `tools/summarise_evidence.py`.",
          "cfg2 = BASELINE.json configs[1]: P4, 54^3 cells, 10 218 313 dofs.", ""]
     # ---- bench lines
-    for nm in ("bench_line", "bench_generic", "bench_periodic_x", "bench_periodic_xyz"):
+    for nm in ("bench_line", "bench_generic", "bench_periodic_x", "bench_periodic_xyz", "bench_generic_periodic_xyz"):
         p = os.path.join(src, nm + ".json")
         if os.path.exists(p):
             txt = [l for l in open(p).read().splitlines() if l.startswith("{")]
