@@ -14,6 +14,17 @@ namespace wf {
 
 static inline unsigned capped_grid(size_t n, unsigned block)
 {
+  // One entry per thread up to 2^22 workgroups (the loops below are grid-stride, so any n is covered).  A grid capped
+  // at 8 workgroups per CU, every thread looping ~10 times, measured 10 % slower on the streaming kernels in the
+  // sustained RK4 loop (stage kernel 0.152 -> 0.136 ms, step 1.372 -> 1.308 ms): fresh waves keep more independent
+  // requests in flight than the iterations of a resident one.
+  size_t g = (n + block - 1) / block;
+  const size_t cap = (size_t)1 << 22;
+  return (unsigned)(g < cap ? (g ? g : 1) : cap);
+}
+// reductions (one atomic per workgroup): 8 workgroups per CU
+static inline unsigned reduction_grid(size_t n, unsigned block)
+{
   size_t g = (n + block - 1) / block;
   const size_t cap = 256u * 8u;
   return (unsigned)(g < cap ? (g ? g : 1) : cap);
@@ -386,7 +397,7 @@ int wf_dot(int64_t n, const double* d_x, const double* d_y, double* d_result, vo
 {
   WF_HIP_CHECK(hipMemsetAsync(d_result, 0, sizeof(double), (hipStream_t)stream));
   if (n <= 0) return WF_OK;
-  hipLaunchKernelGGL(k_dot, dim3(capped_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, n, d_x, d_y, d_result);
+  hipLaunchKernelGGL(k_dot, dim3(reduction_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, n, d_x, d_y, d_result);
   WF_LAUNCH_CHECK();
   return WF_OK;
 }
@@ -448,7 +459,7 @@ int rk4_stage_impl(int64_t n, double bdt, double adt_next, int has_next, double*
   // in the same launch, or the scalar kernel for unaligned vectors
   const int64_t nvec = vec ? n / 2 : n;
   const int ntail = vec ? (int)(n - 2 * nvec) : 0;
-  const unsigned grid = capped_grid(std::max<int64_t>(nvec, 1), 256);
+  const unsigned grid = capped_grid((size_t)std::max<int64_t>(nvec, 1), 256);
 #define WF_STAGE(VEC, NEXT, NT_, BC_) \
   hipLaunchKernelGGL((wf::k_rk4_stage<VEC, NEXT, NT_, BC_>), dim3(grid), dim3(256), 0, st, nvec, ntail, a)
   if (vec) {
