@@ -82,6 +82,11 @@ struct MassArgs {
   double* y;
 };
 
+// Diagnostic build only (tools/variant_lib.sh ... -DWF_MASS_ABL=<mask>; results are wrong): 1 = plain stores instead
+// of the y atomics, 2 = no y memory operation, 4 = no x loads, 8 = no det J loads, 16 = no passes, 32 = no table loads
+#ifndef WF_MASS_ABL
+#define WF_MASS_ABL 0
+#endif
 #ifndef WF_MASS_FLUSH_SLOTS
 #define WF_MASS_FLUSH_SLOTS 2
 #endif
@@ -141,7 +146,7 @@ __global__ __launch_bounds__((MassLayout<P, BX, BY>::WG), 2) void k_mass_march(M
   auto load_d = [&](double (&d)[n], int l) {
     const double* dp = a.detJ + ((item * (size_t)a.lz + l) * n) * (size_t)(CB * n2) + (active ? cl * n2 + pq : 0);
 #pragma unroll
-    for (int k = 0; k < n; ++k) d[k] = __builtin_nontemporal_load(dp + (size_t)k * (CB * n2));
+    for (int k = 0; k < n; ++k) d[k] = (WF_MASS_ABL & 8) ? 1.0 + k : __builtin_nontemporal_load(dp + (size_t)k * (CB * n2));
   };
 
   // ---- prologue ---------------------------------------------------------------------------
@@ -195,11 +200,14 @@ __global__ __launch_bounds__((MassLayout<P, BX, BY>::WG), 2) void k_mass_march(M
       const double v = Tb[pos];
       Tb[pos] = 0.0;
       if (off < 0) continue;
-#if defined(WF_MASS_ABL) && WF_MASS_ABL == 1
+#if WF_MASS_ABL & 1
       a.y[gbase + off] = v;
-#elif defined(WF_MASS_ABL) && WF_MASS_ABL == 2
+#elif WF_MASS_ABL & 2
       asm volatile("" ::"v"(v));
 #else
+      // (measured: a plain y[g] += v for the positions strictly inside the tile, which belong to this work item
+      // alone, is 3.5x SLOWER -- P4 0.117 -> 0.408 ms: the load -> add -> store chain waits in the flush, the
+      // atomic is fire-and-forget)
       unsafeAtomicAdd(a.y + gbase + off, v);
 #endif
     }
@@ -253,9 +261,9 @@ __global__ __launch_bounds__((MassLayout<P, BX, BY>::WG), 2) void k_mass_march(M
     for (int m = 0; m < NPOS; ++m) {
       const int pos = t + WG * m;
       const int32_t off = pos < P * TP ? sIdx[ring(rbx, pos)] : -1;
-      xn[m] = a.x[gbase + (off >= 0 ? off : 0)];
+      xn[m] = (WF_MASS_ABL & 4) ? 1.0 + m : a.x[gbase + (off >= 0 ? off : 0)];
       const int e = e_in + pos;
-      tn[m] = pat[e <= Emax ? e : Emax];
+      tn[m] = (WF_MASS_ABL & 32) ? e : pat[e <= Emax ? e : Emax];
     }
     if (has_next) load_d(dnext, ln);
     WF_MSTR(1);
@@ -263,7 +271,8 @@ __global__ __launch_bounds__((MassLayout<P, BX, BY>::WG), 2) void k_mass_march(M
     // (b) the five passes of the element kernel, wave-private, with the previous layer's flush between them
     double in[n], out[n];
     flush_slot(Tprev, l, 0);
-    if (active) {
+    const bool run_passes = active && !(WF_MASS_ABL & 16);
+    if (run_passes) {
       // X: lane (j, k) = (p0, p1)
 #pragma unroll
       for (int c = 0; c < n; ++c) in[c] = Ub[ucell + p1 * TP + p0 * TX + c];
@@ -274,7 +283,7 @@ __global__ __launch_bounds__((MassLayout<P, BX, BY>::WG), 2) void k_mass_march(M
     }
     WF_MSTR(2);
     flush_slot(Tprev, l, 1);
-    if (active) {
+    if (run_passes) {
       // Y: lane (qi, k) = (p0, p1)
 #pragma unroll
       for (int c = 0; c < n; ++c) in[c] = A[(p1 * n + c) * n + p0];
@@ -285,7 +294,7 @@ __global__ __launch_bounds__((MassLayout<P, BX, BY>::WG), 2) void k_mass_march(M
     }
     WF_MSTR(3);
     flush_slot(Tprev, l, 2);
-    if (active) {
+    if (run_passes) {
       // Z: lane (qi, qj) = (p0, p1): forward, times det J w, transposed
 #pragma unroll
       for (int c = 0; c < n; ++c) in[c] = A[(c * n + p1) * n + p0];
@@ -299,7 +308,7 @@ __global__ __launch_bounds__((MassLayout<P, BX, BY>::WG), 2) void k_mass_march(M
     }
     WF_MSTR(4);
     flush_slot(Tprev, l, 3);
-    if (active) {
+    if (run_passes) {
       // Y^T: lane (qi, k) = (p0, p1)
 #pragma unroll
       for (int q = 0; q < n; ++q) in[q] = A[(p1 * n + q) * n + p0];
@@ -310,7 +319,7 @@ __global__ __launch_bounds__((MassLayout<P, BX, BY>::WG), 2) void k_mass_march(M
     }
     WF_MSTR(5);
     flush_slot(Tprev, l, 4);
-    if (active) {
+    if (run_passes) {
       // X^T: lane (j, k) = (p0, p1); planes 0..P-1 -> O, plane P -> carry, plane 0 picks up the previous carry
 #pragma unroll
       for (int q = 0; q < n; ++q) in[q] = A[(p1 * n + p0) * n + q];
