@@ -82,7 +82,9 @@ def test_cg_dense_mass_vs_numpy(gpu, oracle, p, n):
         x = torch.zeros(om.ndofs, dtype=torch.float64, device=gpu)
         Aop = op if mode == "handle" else (lambda v, y: op(v, y))
         its, res = la.cg(x, torch.from_numpy(b).to(gpu), Aop, kmax=200, rtol=1e-10)
-        assert abs(its - k_np) <= 1, (its, k_np)
+        # the operator sums its contributions with atomics (order varies from run to run): near convergence the
+        # iteration count of a 126-iteration solve moves by a few steps with the rounding
+        assert abs(its - k_np) <= max(3, k_np // 25), (its, k_np)
         assert res < 1e-10
         assert np.abs(x.cpu().numpy() - xs).max() <= 1e-7 * np.abs(xs).max()
     # non-zero initial guess: the iteration starts from r = b - A x0
@@ -123,7 +125,7 @@ def test_cg_periodic_partition_native_rccl(gpu, oracle):
     x = torch.zeros_like(b)
     its, res = la.cg(x, b, op, kmax=300, rtol=1e-9, updater=vu)
     _, k_np = numpy_cg(A, bg, 300, 1e-9)
-    assert abs(its - k_np) <= 1 and res < 1e-9, (its, k_np, res)
+    assert abs(its - k_np) <= max(3, k_np // 25) and res < 1e-9, (its, k_np, res)   # (atomics: see test_cg_dense_mass_vs_numpy)
     assert np.abs(x.cpu().numpy()[owned] - xs[l2g[owned]]).max() <= 1e-7 * np.abs(xs).max()
     comm.close()
 

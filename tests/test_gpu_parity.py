@@ -330,6 +330,32 @@ def test_dense_mass_long_columns(gpu, oracle, p, block, lz):
     assert relerr(y.cpu().numpy(), 2 * yref) <= TOL
 
 
+@pytest.mark.parametrize("p,n", [(1, (9, 9, 9)), (2, (9, 5, 7)), (3, (5, 5, 5)), (4, (5, 3, 9)), (6, (3, 3, 5))])
+def test_marching_kernels_are_repeatable(gpu, p, n):
+    """The cells of a layer are summed in an LDS tile (ds_add_f64) and the work items add to y with global atomics:
+    the order of the additions differs from run to run, the data must not.  100 applies of the stiffness operator
+    (box and arbitrary dofmap) and of the dense mass on a perturbed mesh agree to rounding (1e-14 of the largest
+    entry); a race in the double-buffered LDS tiles or the index ring would show as an occasional O(1) deviation."""
+    import torch
+    import wave_fenics_amd as w
+    mesh = w.create_box(n, perturb=0.2)
+    V = w.create_functionspace(mesh, p)
+    ops = [w.StiffnessOperator(V, p, structured=True),
+           w.StiffnessOperator(V, p, structured=False, tuning={"kernel": "march"}),
+           w.MassOperator(V, p, variant="equispaced", quad="gauss_jacobi", qdegree=2 * p, tuning={"kernel": "march"})]
+    x = torch.rand(V.ndofs, dtype=torch.float64, device=gpu)
+    for op in ops:
+        ref, worst = None, 0.0
+        for _ in range(100):
+            y = torch.zeros_like(x)
+            op.apply(x, y) if hasattr(op, "apply") else op(x, y)
+            if ref is None:
+                ref = y.clone()
+            else:
+                worst = max(worst, float((y - ref).abs().max() / ref.abs().max()))
+        assert worst <= 1e-14, (p, op.kernel, worst)
+
+
 @pytest.mark.parametrize("p", [2, 3, 4])
 def test_x_slowest_tensor_order(gpu, oracle, p):
     """The DOLFINx-facing axis-order hazard: a caller whose tensor index is x-SLOWEST
