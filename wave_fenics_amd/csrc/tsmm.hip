@@ -394,18 +394,17 @@ static int launch_tsmm_t(int layout, int64_t ncells, int Kfull, int N, int n0, i
         main_tiles = ntiles - rem;
         break;
       }
-  auto go = [&](auto kern, size_t& set) -> int {
-    if (lds > 64 * 1024 && lds > set) {
+  // (the attribute is set on every launch that needs more than 64 KB: a per-process cache of "already set" is wrong for a
+  // second device in the process and racy between host threads, and the call costs well under a microsecond)
+  auto go = [&](auto kern) -> int {
+    if (lds > 64 * 1024)
       WF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      set = lds;
-    }
     hipLaunchKernelGGL(kern, dim3(nb), dim3(64 * kTsmmWaves), lds, s, ncells, Kfull, N, n0, k0, K, main_tiles, tail_ct, in, phi, out);
     return WF_OK;
   };
-  static size_t set[4] = {0, 0, 0, 0};
   int rc;
-  if (layout == 0) rc = k0 > 0 ? go(k_tsmm<NT, 0, true>, set[1]) : go(k_tsmm<NT, 0, false>, set[0]);
-  else rc = k0 > 0 ? go(k_tsmm<NT, 1, true>, set[3]) : go(k_tsmm<NT, 1, false>, set[2]);
+  if (layout == 0) rc = k0 > 0 ? go(k_tsmm<NT, 0, true>) : go(k_tsmm<NT, 0, false>);
+  else rc = k0 > 0 ? go(k_tsmm<NT, 1, true>) : go(k_tsmm<NT, 1, false>);
   if (rc != WF_OK) return rc;
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {

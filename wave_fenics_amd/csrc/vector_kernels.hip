@@ -72,6 +72,33 @@ __global__ void k_fill(int64_t n, double v, double* __restrict__ out)
   for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (int64_t)gridDim.x * blockDim.x)
     out[g] = v;
 }
+// 16-byte forms of fill / axpy / scale (aligned arrays; the odd last entry by thread 0 of the last workgroup)
+__global__ void k_fill2(int64_t npairs, int tail, double v, double* out)
+{
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g < npairs) reinterpret_cast<double2*>(out)[g] = make_double2(v, v);
+  if (tail && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) out[2 * npairs] = v;
+}
+__global__ void k_axpy2(int64_t npairs, int tail, double alpha, const double* x, const double* y, double* r)
+{
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g < npairs) {   // r may alias y (or x): every thread reads its entry before it writes it
+    const double2 xx = reinterpret_cast<const double2*>(x)[g], yy = reinterpret_cast<const double2*>(y)[g];
+    reinterpret_cast<double2*>(r)[g] = make_double2(xx.x * alpha + yy.x, xx.y * alpha + yy.y);
+  }
+  if (tail && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) r[2 * npairs] = x[2 * npairs] * alpha + y[2 * npairs];
+}
+__global__ void k_scale2(int64_t npairs, int tail, double alpha, double* x)
+{
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g < npairs) {
+    double2 v = reinterpret_cast<double2*>(x)[g];
+    v.x *= alpha;
+    v.y *= alpha;
+    reinterpret_cast<double2*>(x)[g] = v;
+  }
+  if (tail && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) x[2 * npairs] *= alpha;
+}
 // kernels::axpy of common/LinearGLL.hpp:28-33: r = x*alpha + y (r may alias y)
 __global__ void k_axpy(int64_t n, double alpha, const double* x, const double* y, double* r)
 {
@@ -348,22 +375,35 @@ int wf_copy(int64_t n, const double* d_in, double* d_out, void* stream)
 int wf_fill(int64_t n, double value, double* d_out, void* stream)
 {
   if (n <= 0) return WF_OK;
-  hipLaunchKernelGGL(k_fill, dim3(capped_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, n, value, d_out);
+  const int64_t np2 = n / 2;
+  if ((reinterpret_cast<uintptr_t>(d_out) & 15) == 0 && np2 > 0 && np2 < ((int64_t)1 << 30))
+    hipLaunchKernelGGL(k_fill2, dim3((unsigned)((np2 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, np2, (int)(n - 2 * np2), value, d_out);
+  else
+    hipLaunchKernelGGL(k_fill, dim3(capped_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, n, value, d_out);
   WF_LAUNCH_CHECK();
   return WF_OK;
 }
 int wf_axpy(int64_t n, double alpha, const double* d_x, const double* d_y, double* d_r, void* stream)
 {
   if (n <= 0) return WF_OK;
-  hipLaunchKernelGGL(k_axpy, dim3(capped_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, n, alpha, d_x, d_y,
-                     d_r);
+  const int64_t np2 = n / 2;
+  if (((reinterpret_cast<uintptr_t>(d_x) | reinterpret_cast<uintptr_t>(d_y) | reinterpret_cast<uintptr_t>(d_r)) & 15) == 0 && np2 > 0 &&
+      np2 < ((int64_t)1 << 30))
+    hipLaunchKernelGGL(k_axpy2, dim3((unsigned)((np2 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, np2, (int)(n - 2 * np2), alpha, d_x,
+                       d_y, d_r);
+  else
+    hipLaunchKernelGGL(k_axpy, dim3(capped_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, n, alpha, d_x, d_y, d_r);
   WF_LAUNCH_CHECK();
   return WF_OK;
 }
 int wf_scale(int64_t n, double alpha, double* d_x, void* stream)
 {
   if (n <= 0) return WF_OK;
-  hipLaunchKernelGGL(k_scale, dim3(capped_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, n, alpha, d_x);
+  const int64_t np2 = n / 2;
+  if ((reinterpret_cast<uintptr_t>(d_x) & 15) == 0 && np2 > 0 && np2 < ((int64_t)1 << 30))
+    hipLaunchKernelGGL(k_scale2, dim3((unsigned)((np2 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, np2, (int)(n - 2 * np2), alpha, d_x);
+  else
+    hipLaunchKernelGGL(k_scale, dim3(capped_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, n, alpha, d_x);
   WF_LAUNCH_CHECK();
   return WF_OK;
 }
