@@ -36,6 +36,7 @@ def main():
     y = torch.zeros(V.ndofs, dtype=torch.float64, device=dev)
     ops = {}
     ops["generic"] = w.StiffnessOperator(V, p, structured=False)
+    ops["batch"] = w.StiffnessOperator(V, p, structured=False, tuning={"kernel": "batch"})
     for spec in sys.argv[1:]:
         # block:bx,by,bz   single-pass block kernel;  march:variant[:lz]   one-thread-per-column marching kernel
         # (variant 0..2) or the k-split kernel (variant 3);  ks:bx,by[:lz]   k-split kernel with that cross-section

@@ -413,6 +413,121 @@ __global__ __launch_bounds__(256) void k_stiffness_generic_u(int ncells, const i
   }
 }
 
+// The same kernel as a persistent workgroup that walks batches and carries the NEXT batch's unique-dof indices in
+// registers: the x gather of a batch is a chain of three dependent loads (uoff -> uniq -> x), and the ablation masks
+// showed it costs as much as the whole geometry stream (P4, 10 M dofs: 0.261 ms; without the x loads 0.202, with the
+// geometry served from L2 0.204).  With the indices fetched one batch ahead the x loads are issued at the top of a
+// batch together with its geometry: one memory latency per batch instead of two and a half.  All loads of the loop
+// are unconditional on clamped addresses (a guard is a branch; at its join the compiler waits for every pending
+// load), the indices double as the scatter addresses of the batch.
+template <int P>
+__global__ __launch_bounds__(256) void k_stiffness_generic_up(int ncells, int nbatch, const int32_t* __restrict__ uoff,
+                                                              const int32_t* __restrict__ uniq, const uint16_t* __restrict__ loc,
+                                                              const double2* __restrict__ G6blk, const double* __restrict__ dD,
+                                                              DMat dm, double coeff, const double* __restrict__ x,
+                                                              double* __restrict__ y)
+{
+  constexpr int n = P + 1, n2 = n * n, nd = n * n2;
+  constexpr int CB = 256 / n2, NT = CB * n2;
+  constexpr int NFLAT = (CB * nd + 255) / 256;   // element-local dofs per thread; also bounds the unique dofs per thread
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* U = smem;                 // [CB][nd]
+  double* Fr = U + CB * nd;         // [CB][nd]; also the unique-dof tile before phase 1 and after phase 2
+  double* Fs = Fr + CB * nd;        // [CB][nd]
+  double* sD = Fs + CB * nd;        // [n][n]
+
+  const int t = threadIdx.x;
+  const bool active = t < NT;
+  const int cl = t / n2, ji = t % n2, j = ji / n, i = ji % n;
+  if (t < n * n) sD[t] = dD[t];
+
+  // unique-dof indices of a batch -> registers (entry u = t + 256 m; past the list: its last entry)
+  auto load_uniq = [&](int32_t (&uq)[NFLAT], int& nu, int b) {
+    const int u0 = uoff[b];
+    nu = uoff[b + 1] - u0;
+#pragma unroll
+    for (int m = 0; m < NFLAT; ++m) {
+      const int u = t + 256 * m;
+      uq[m] = uniq[u0 + (u < nu ? u : nu - 1)];
+    }
+  };
+  int32_t uqa[NFLAT], uqb[NFLAT];
+  int nua = 0, nub = 0;
+  int batch = blockIdx.x;
+  if (batch < nbatch) load_uniq(uqa, nua, batch);
+
+  auto one = [&](int32_t (&uq)[NFLAT], int nu, int32_t (&uqn)[NFLAT], int& nun, int b) {
+    const int cell0 = b * CB;
+    // (a) this batch's x values, geometry and local positions; the next batch's indices
+    double xr[NFLAT];
+#pragma unroll
+    for (int m = 0; m < NFLAT; ++m) xr[m] = x[uq[m]];
+    double2 g[n][3];
+    {
+      const double2* gp = G6blk + ((size_t)b * n * 3) * (size_t)NT + (active ? t : NT - 1);
+#pragma unroll
+      for (int k = 0; k < n; ++k)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) g[k][p] = load_stream(gp + (size_t)(k * 3 + p) * NT);
+    }
+    uint16_t lc[NFLAT];
+    const int nvalid = min(CB, ncells - cell0) * nd;
+#pragma unroll
+    for (int m = 0; m < NFLAT; ++m) {
+      const int pos = t + 256 * m;
+      const uint16_t v = loc[(size_t)cell0 * nd + (pos < nvalid ? pos : 0)];
+      lc[m] = pos < nvalid ? v : (uint16_t)0xFFFF;
+    }
+    const int bn = b + (int)gridDim.x;
+    load_uniq(uqn, nun, bn < nbatch ? bn : b);
+    // (b) unique tile -> LDS -> element-local layout
+#pragma unroll
+    for (int m = 0; m < NFLAT; ++m) {
+      const int u = t + 256 * m;
+      if (u < nu) Fr[u] = xr[m];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < NFLAT; ++m) {
+      const int pos = t + 256 * m;
+      if (pos < CB * nd) U[pos] = lc[m] != 0xFFFF ? Fr[lc[m]] : 0.0;
+    }
+    __syncthreads();
+    double out[n];
+    stiffness_column<P>(U + cl * nd, n2, n, Fr + cl * nd, Fs + cl * nd, sD, dm, g, coeff, i, j, active, out, 0);
+    if (active) {
+#pragma unroll
+      for (int k = 0; k < n; ++k) U[cl * nd + k * n2 + ji] = out[k];
+    }
+    __syncthreads();   // phase 2 has read Fr/Fs, U holds the element results
+#pragma unroll
+    for (int m = 0; m < NFLAT; ++m) {
+      const int u = t + 256 * m;
+      if (u < nu) Fr[u] = 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < NFLAT; ++m) {
+      const int pos = t + 256 * m;
+      if (lc[m] != 0xFFFF) atomicAdd(&Fr[lc[m]], U[pos]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < NFLAT; ++m) {
+      const int u = t + 256 * m;
+      if (u < nu) unsafeAtomicAdd(&y[uq[m]], Fr[u]);
+    }
+    __syncthreads();   // Fr is the next batch's unique tile
+  };
+  while (batch < nbatch) {
+    one(uqa, nua, uqb, nub, batch);
+    batch += gridDim.x;
+    if (batch >= nbatch) break;
+    one(uqb, nub, uqa, nua, batch);
+    batch += gridDim.x;
+  }
+}
+
 template <int P>
 __global__ __launch_bounds__(256) void k_stiffness_box(int nx, int ny, int nz, int bx, int by, int bz,
                                                        const double2* __restrict__ G6blk,
@@ -924,6 +1039,9 @@ static int launch_stiffness_generic_t(int ncells, const int32_t* d_dofmap, const
   return WF_OK;
 }
 
+#ifndef WF_GENERIC_PIPELINED
+#define WF_GENERIC_PIPELINED 1
+#endif
 template <int P>
 static int launch_stiffness_generic_u_t(int ncells, const int32_t* d_uoff, const int32_t* d_uniq,
                                         const uint16_t* d_loc, const double* d_G6blk, const double* d_D,
@@ -932,6 +1050,18 @@ static int launch_stiffness_generic_u_t(int ncells, const int32_t* d_uoff, const
   constexpr int n = P + 1, nd = n * n * n, CB = 256 / (n * n);
   const unsigned nb = (unsigned)((ncells + CB - 1) / CB);
   const size_t lds = (size_t)(3 * CB * nd + n * n) * sizeof(double);
+#if WF_GENERIC_PIPELINED
+  if (ablate_flags() == 0) {
+    // persistent workgroups, as many as fit the chip at this kernel's register / LDS use (4 per CU at P <= 4)
+    int per_cu = 0;
+    WF_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_stiffness_generic_up<P>, 256, lds));
+    const unsigned grid = std::min<unsigned>(nb, (unsigned)std::max(1, per_cu) * 256u);
+    hipLaunchKernelGGL(k_stiffness_generic_up<P>, dim3(grid), dim3(256), lds, s, ncells, (int)nb, d_uoff, d_uniq, d_loc,
+                       reinterpret_cast<const double2*>(d_G6blk), d_D, dm, coeff, d_x, d_y);
+    WF_LAUNCH_CHECK();
+    return WF_OK;
+  }
+#endif
   hipLaunchKernelGGL(k_stiffness_generic_u<P>, dim3(nb), dim3(256), lds, s, ncells, d_uoff, d_uniq, d_loc,
                      reinterpret_cast<const double2*>(d_G6blk), d_D, dm, coeff, d_x, d_y, ablate_flags());
   WF_LAUNCH_CHECK();
