@@ -63,9 +63,11 @@ def main():
             dm = dp[dm]
         m2 = w.BoxMesh(mesh.n, mesh.x, np.ascontiguousarray(gd))
         V2 = w.FunctionSpace(m2, p, np.ascontiguousarray(dm), w.IndexMap(V.ndofs), V.lattice, structured=False)
-        op = w.StiffnessOperator(V2, p, structured=False)
+        kern = os.environ.get("KERNEL")
+        op = w.StiffnessOperator(V2, p, structured=False, tuning={"kernel": kern} if kern else None)
+        name = f"{name} [{op.kernel}]"
         t = time_op(op, x, y)
-        print(f"{name:28s} {t:8.3f} ms   {op.alg_bytes()/t/1e6:8.0f} GB/s alg   frac {op.alg_bytes()/t/1e6/8000:.3f}", flush=True)
+        print(f"{name:44s} {t:8.3f} ms   {op.alg_bytes()/t/1e6:8.0f} GB/s alg   frac {op.alg_bytes()/t/1e6/8000:.3f}", flush=True)
         del op
 
 

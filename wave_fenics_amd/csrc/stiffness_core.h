@@ -26,6 +26,11 @@ __device__ __forceinline__ double2 load_stream(const double2* p)
 // Phase 1: reference gradient at the quadrature points, times G -> Fr, Fs (LDS) and ft
 // (registers).  A workgroup barrier separates it from phase 2, which applies D^T:
 // out[k] = (K_cell u)[i, j, k].  The geometry registers g are dead after phase 1.
+// P7: the z rows of D come from LDS (broadcast reads) -- as 128 SGPRs they spill (224 v_readlane per layer in the
+// batch kernel: 0.189 -> 0.1755 ms with LDS rows; P6: 0.201 -> 0.207, P5 unchanged, so P <= 6 keeps the SGPRs)
+#ifndef WF_CORE_DZ_LDS
+#define WF_CORE_DZ_LDS 1
+#endif
 template <int P>
 __device__ __forceinline__ void stiffness_phase1(const double* __restrict__ U, int sk, int sj,
                                                  double* __restrict__ Fr, double* __restrict__ Fs,
@@ -51,7 +56,7 @@ __device__ __forceinline__ void stiffness_phase1(const double* __restrict__ U, i
       for (int a = 0; a < n; ++a) {
         ur += di[a] * U[k * sk + j * sj + a];
         us += dj[a] * U[k * sk + a * sj + i];
-        ut += dm.v[k * n + a] * ru[a];
+        ut += (WF_CORE_DZ_LDS && P >= 7 ? sD[k * n + a] : dm.v[k * n + a]) * ru[a];
       }
       const double g00 = g[k][0].x, g01 = g[k][0].y, g02 = g[k][1].x, g11 = g[k][1].y,
                    g12 = g[k][2].x, g22 = g[k][2].y;
@@ -86,7 +91,7 @@ __device__ __forceinline__ void stiffness_phase2(const double* __restrict__ Fr, 
       for (int a = 0; a < n; ++a) {
         s += dti[a] * Fr[k * n2 + j * n + a];
         s += dtj[a] * Fs[k * n2 + a * n + i];
-        s += dm.v[a * n + k] * ft[a];
+        s += (WF_CORE_DZ_LDS && P >= 7 ? sD[a * n + k] : dm.v[a * n + k]) * ft[a];
       }
       out[k] = s;
     }
