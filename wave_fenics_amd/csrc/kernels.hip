@@ -528,6 +528,143 @@ __global__ __launch_bounds__(256) void k_stiffness_generic_up(int ncells, int nb
   }
 }
 
+// Fully pipelined form (P <= 4: two geometry register sets fit at two workgroups per CU): everything batch b + s needs (s = the grid size) --
+// geometry, x values, local positions -- is requested while batch b computes, its unique-dof indices one batch
+// earlier, the two scalars that locate them one batch earlier still.  There is no `has_next` anywhere: a batch past
+// the end is the last batch again (redundant reads, never stored), so the wait counts the compiler derives stay
+// exact (stiffness_march.hip on what a uniform branch around a prefetch costs).
+template <int P>
+__global__ __launch_bounds__(256) void k_stiffness_generic_up2(int ncells, int nbatch, const int32_t* __restrict__ uoff,
+                                                               const int32_t* __restrict__ uniq, const uint16_t* __restrict__ loc,
+                                                               const double2* __restrict__ G6blk, const double* __restrict__ dD,
+                                                               DMat dm, double coeff, const double* __restrict__ x,
+                                                               double* __restrict__ y)
+{
+  constexpr int n = P + 1, n2 = n * n, nd = n * n2;
+  constexpr int CB = 256 / n2, NT = CB * n2;
+  constexpr int NFLAT = (CB * nd + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* U = smem;
+  double* Fr = U + CB * nd;
+  double* Fs = Fr + CB * nd;
+  double* sD = Fs + CB * nd;
+
+  const int t = threadIdx.x;
+  const bool active = t < NT;
+  const int cl = t / n2, ji = t % n2, j = ji / n, i = ji % n;
+  if (t < n * n) sD[t] = dD[t];
+  const int stride = (int)gridDim.x;
+  auto clampb = [&](int b) { return b < nbatch ? b : nbatch - 1; };
+
+  // unique-dof indices of the batch whose list is uniq[u0 .. u0 + nu) -> registers (past the list: its last entry)
+  auto load_uniq = [&](int32_t (&uq)[NFLAT], int u0, int nu) {
+#pragma unroll
+    for (int m = 0; m < NFLAT; ++m) {
+      const int u = t + 256 * m;
+      uq[m] = uniq[u0 + (u < nu ? u : nu - 1)];
+    }
+  };
+  auto load_batch = [&](double (&xr)[NFLAT], double2 (&g)[n][3], uint16_t (&lc)[NFLAT], const int32_t (&uq)[NFLAT], int b) {
+#pragma unroll
+    for (int m = 0; m < NFLAT; ++m) xr[m] = x[uq[m]];
+    const double2* gp = G6blk + ((size_t)b * n * 3) * (size_t)NT + (active ? t : NT - 1);
+#pragma unroll
+    for (int k = 0; k < n; ++k)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) g[k][p] = load_stream(gp + (size_t)(k * 3 + p) * NT);
+    const int cell0 = b * CB, nvalid = min(CB, ncells - cell0) * nd;
+#pragma unroll
+    for (int m = 0; m < NFLAT; ++m) {
+      const int pos = t + 256 * m;
+      const uint16_t v = loc[(size_t)cell0 * nd + (pos < nvalid ? pos : 0)];
+      lc[m] = pos < nvalid ? v : (uint16_t)0xFFFF;
+    }
+  };
+
+  int batch = blockIdx.x;
+  if (batch >= nbatch) return;
+  // list locations (scalars) of batches b, b + s, b + 2 s; vectors in two sets that swap roles (loop unrolled by two)
+  int b1 = clampb(batch + stride), b2 = clampb(batch + 2 * stride);
+  int u0c = uoff[batch], nuc = uoff[batch + 1] - u0c;
+  int u0n = uoff[b1], nun = uoff[b1 + 1] - u0n;
+  int u0nn = uoff[b2], nunn = uoff[b2 + 1] - u0nn;
+  int32_t uqA[NFLAT], uqB[NFLAT];
+  double xA[NFLAT], xB[NFLAT];
+  double2 gA[n][3], gB[n][3];
+  uint16_t lcA[NFLAT], lcB[NFLAT];
+  load_uniq(uqA, u0c, nuc);
+  load_uniq(uqB, u0n, nun);
+  load_batch(xA, gA, lcA, uqA, batch);
+
+  // batch b sits in (xr, g, lc); uqn holds the indices of batch b + s, into which (xn, gn, lcn) are loaded; uq (the
+  // indices of batch b, no longer needed: its scatter re-reads them from L2) is refilled with those of batch b + 2 s
+  auto one = [&](int32_t (&uq)[NFLAT], double (&xr)[NFLAT], double2 (&g)[n][3], uint16_t (&lc)[NFLAT], int32_t (&uqn)[NFLAT],
+                 double (&xn)[NFLAT], double2 (&gn)[n][3], uint16_t (&lcn)[NFLAT], int b) {
+    const int nu = nuc, u0 = u0c;
+    // (a) unique tile -> LDS (consumes xr) -> element-local layout
+#pragma unroll
+    for (int m = 0; m < NFLAT; ++m) {
+      const int u = t + 256 * m;
+      if (u < nu) Fr[u] = xr[m];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < NFLAT; ++m) {
+      const int pos = t + 256 * m;
+      if (pos < CB * nd) U[pos] = lc[m] != 0xFFFF ? Fr[lc[m]] : 0.0;
+    }
+    __syncthreads();
+    // (b) this batch's scatter addresses again (L2), then the requests for batch b + s and the indices of b + 2 s,
+    //     then the list location of b + 3 s: all in flight during the phases
+    int32_t us[NFLAT];
+    load_uniq(us, u0, nu);
+    load_batch(xn, gn, lcn, uqn, clampb(b + stride));
+    load_uniq(uq, u0nn, nunn);
+    const int b3 = clampb(b + 3 * stride);
+    const int u0n3 = uoff[b3], nun3 = uoff[b3 + 1] - u0n3;
+    // (c) element kernel
+    double out[n];
+    stiffness_column<P>(U + cl * nd, n2, n, Fr + cl * nd, Fs + cl * nd, sD, dm, g, coeff, i, j, active, out, 0);
+    if (active) {
+#pragma unroll
+      for (int k = 0; k < n; ++k) U[cl * nd + k * n2 + ji] = out[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < NFLAT; ++m) {
+      const int u = t + 256 * m;
+      if (u < nu) Fr[u] = 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < NFLAT; ++m) {
+      const int pos = t + 256 * m;
+      if (lc[m] != 0xFFFF) atomicAdd(&Fr[lc[m]], U[pos]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < NFLAT; ++m) {
+      const int u = t + 256 * m;
+      if (u < nu) unsafeAtomicAdd(&y[us[m]], Fr[u]);
+    }
+    __syncthreads();
+    u0c = u0n;
+    nuc = nun;
+    u0n = u0nn;
+    nun = nunn;
+    u0nn = u0n3;
+    nunn = nun3;
+  };
+  while (true) {
+    one(uqA, xA, gA, lcA, uqB, xB, gB, lcB, batch);
+    batch += stride;
+    if (batch >= nbatch) break;
+    one(uqB, xB, gB, lcB, uqA, xA, gA, lcA, batch);
+    batch += stride;
+    if (batch >= nbatch) break;
+  }
+}
+
 template <int P>
 __global__ __launch_bounds__(256) void k_stiffness_box(int nx, int ny, int nz, int bx, int by, int bz,
                                                        const double2* __restrict__ G6blk,
@@ -1042,6 +1179,9 @@ static int launch_stiffness_generic_t(int ncells, const int32_t* d_dofmap, const
 #ifndef WF_GENERIC_PIPELINED
 #define WF_GENERIC_PIPELINED 1
 #endif
+#ifndef WF_GENERIC_UP2_MAXP
+#define WF_GENERIC_UP2_MAXP 4   // degrees that use the fully pipelined kernel (two geometry register sets; P5, P6 need 256 VGPRs + AGPRs: one wave per SIMD)
+#endif
 template <int P>
 static int launch_stiffness_generic_u_t(int ncells, const int32_t* d_uoff, const int32_t* d_uniq,
                                         const uint16_t* d_loc, const double* d_G6blk, const double* d_D,
@@ -1054,10 +1194,17 @@ static int launch_stiffness_generic_u_t(int ncells, const int32_t* d_uoff, const
   if (ablate_flags() == 0) {
     // persistent workgroups, as many as fit the chip at this kernel's register / LDS use (4 per CU at P <= 4)
     int per_cu = 0;
-    WF_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_stiffness_generic_up<P>, 256, lds));
-    const unsigned grid = std::min<unsigned>(nb, (unsigned)std::max(1, per_cu) * 256u);
-    hipLaunchKernelGGL(k_stiffness_generic_up<P>, dim3(grid), dim3(256), lds, s, ncells, (int)nb, d_uoff, d_uniq, d_loc,
-                       reinterpret_cast<const double2*>(d_G6blk), d_D, dm, coeff, d_x, d_y);
+    if constexpr (P <= WF_GENERIC_UP2_MAXP) {
+      WF_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_stiffness_generic_up2<P>, 256, lds));
+      const unsigned grid = std::min<unsigned>(nb, (unsigned)std::max(1, per_cu) * 256u);
+      hipLaunchKernelGGL(k_stiffness_generic_up2<P>, dim3(grid), dim3(256), lds, s, ncells, (int)nb, d_uoff, d_uniq, d_loc,
+                         reinterpret_cast<const double2*>(d_G6blk), d_D, dm, coeff, d_x, d_y);
+    } else {
+      WF_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_stiffness_generic_up<P>, 256, lds));
+      const unsigned grid = std::min<unsigned>(nb, (unsigned)std::max(1, per_cu) * 256u);
+      hipLaunchKernelGGL(k_stiffness_generic_up<P>, dim3(grid), dim3(256), lds, s, ncells, (int)nb, d_uoff, d_uniq, d_loc,
+                         reinterpret_cast<const double2*>(d_G6blk), d_D, dm, coeff, d_x, d_y);
+    }
     WF_LAUNCH_CHECK();
     return WF_OK;
   }
