@@ -82,14 +82,14 @@ __global__ __launch_bounds__(256, 2) void k_march_idx(int lz, int tile_size, con
   GT gA[n][GW], gB[n][GW];
   auto load_g = [&](GT (&g)[n][GW], int l, int k0 = 0, int k1 = P + 1) {
     if constexpr (OP == OP_STIFFNESS) {
-      const double2* gp = static_cast<const double2*>(geom) + ((item * lz + l) * n * 3) * (size_t)NT + t;
+      const double2* gp = static_cast<const double2*>(geom) + ((item * lz + l) * n * 3) * (size_t)NT + (t < NT ? t : NT - 1);
 #pragma unroll
       for (int k = 0; k < n; ++k)
 #pragma unroll
         for (int p = 0; p < 3; ++p)
           if (k >= k0 && k < k1) g[k][p] = load_stream(gp + (size_t)(k * 3 + p) * NT);
     } else {
-      const double* gp = static_cast<const double*>(geom) + ((item * lz + l) * n) * (size_t)NT + t;
+      const double* gp = static_cast<const double*>(geom) + ((item * lz + l) * n) * (size_t)NT + (t < NT ? t : NT - 1);
 #pragma unroll
       for (int k = 0; k < n; ++k)
         if (k >= k0 && k < k1) g[k][0] = __builtin_nontemporal_load(gp + (size_t)k * NT);
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256, 2) void k_march_idx(int lz, int tile_size, con
   for (int e = t; e < P * TP; e += 256) O[e] = 0.0;
   for (int e = t; e < (P * nl + 1) * TP; e += 256) sIdx[e] = pat[e];
   __syncthreads();
-  if (active) load_g(gA, 0);
+  load_g(gA, 0);
   // ---- prologue: x planes 0..P of the first layer -> LDS ------------------------
 #pragma unroll
   for (int m = 0; m < NPOS0; ++m) {
@@ -121,8 +121,10 @@ __global__ __launch_bounds__(256, 2) void k_march_idx(int lz, int tile_size, con
   const double* Uc = Ux + (P * ly) * TX + P * lx;
 
   [[maybe_unused]] int trace_it = 0;
-  auto layer = [&](GT (&gcur)[n][GW], GT (&gnext)[n][GW], int l) {
-    const bool has_next = l + 1 < nl;
+  // (idle threads load the last thread's geometry instead of branching around the loads; `has_next` is a compile-time
+  // constant of the layer body at P4, a run-time flag below: stiffness_march.hip)
+  auto layer = [&](auto hn_tag, GT (&gcur)[n][GW], GT (&gnext)[n][GW], int l) {
+    const bool has_next = hn_tag;
     WF_ITR(0);
     // (a) next layer's x planes and geometry: in flight during this layer's arithmetic
     // (unconditional loads on clamped addresses -- dead entries and positions past the tile read the item's first
@@ -136,7 +138,7 @@ __global__ __launch_bounds__(256, 2) void k_march_idx(int lz, int tile_size, con
       const int32_t off = pos < P * TP ? sIdx[(P * ln + 1) * TP + pos] : -1;
       xn[m] = x[gbase + (off >= 0 ? off : 0)];
     }
-    if (has_next && active) load_g(gnext, l + 1, 0, G1);
+    if (has_next) load_g(gnext, l + 1, 0, G1);
 
     WF_ITR(1);
     // (b) element kernels of the layer
@@ -145,7 +147,7 @@ __global__ __launch_bounds__(256, 2) void k_march_idx(int lz, int tile_size, con
       double ft[n];
       stiffness_phase1<P>(Uc, TP, TX, Fr + cl * nd, Fs + cl * nd, sD, dm, gcur, coeff, i, j, active, ft);
       __syncthreads();
-      if (kSpread && has_next && active) load_g(gnext, l + 1, G1, G2);
+      if (kSpread && has_next) load_g(gnext, l + 1, G1, G2);
       stiffness_phase2<P>(Fr + cl * nd, Fs + cl * nd, sD, dm, ft, i, j, active, out);
     }
     WF_ITR(2);
@@ -207,7 +209,7 @@ __global__ __launch_bounds__(256, 2) void k_march_idx(int lz, int tile_size, con
       rotate();
       __builtin_amdgcn_sched_barrier(0);
       WF_ITR(4);
-      if (kSpread && has_next && active) load_g(gnext, l + 1, G2, n);
+      if (kSpread && has_next) load_g(gnext, l + 1, G2, n);
       flush();
     }
     WF_ITR(5);
@@ -215,9 +217,21 @@ __global__ __launch_bounds__(256, 2) void k_march_idx(int lz, int tile_size, con
 
     __syncthreads();
   };
+  using HasNext = std::integral_constant<bool, true>;
+  using IsLast = std::integral_constant<bool, false>;
   for (int l = 0; l < nl; l += 2) {
-    layer(gA, gB, l);
-    if (l + 1 < nl) layer(gB, gA, l + 1);
+    if constexpr (P < 4) {
+      layer(l + 1 < nl, gA, gB, l);
+      if (l + 1 < nl) layer(l + 2 < nl, gB, gA, l + 1);
+    } else if (l + 1 < nl) {
+      layer(HasNext{}, gA, gB, l);
+      if (l + 2 < nl)
+        layer(HasNext{}, gB, gA, l + 1);
+      else
+        layer(IsLast{}, gB, gA, l + 1);
+    } else {
+      layer(IsLast{}, gA, gB, l);
+    }
   }
 
   // ---- epilogue: the last (carried) plane ------------------------------------
@@ -268,8 +282,12 @@ static int launch_t(const MarchPlanDev& pd, const double* d_G6blk, const double*
 }
 
 // the stiffness operator runs the k-split kernel (stiffness_march_ks.hip) at P >= 5
-// P >= 4 runs the k-split kernel (cfg2, any dofmap: k_march_idx<4,5,2> 0.208 ms, k_march_ks<4,5,1,true> 0.197 ms)
-static bool march_idx_uses_ks(int P) { return P >= 4; }
+// P >= 5 runs the k-split kernel.  P4, any dofmap, cfg2: k_march_idx<4,5,2> 0.204 ms, k_march_ks<4,5,1,true> 0.208 ms
+// (-DWF_IDX_KS_MINP=4 selects the latter)
+#ifndef WF_IDX_KS_MINP
+#define WF_IDX_KS_MINP 5
+#endif
+static bool march_idx_uses_ks(int P) { return P >= WF_IDX_KS_MINP; }
 
 // the cross-sections with BX * BY == floor(256 / n^2) cells (geometry batch layout)
 void march_idx_shape(int kind, int P, int* bx, int* by)
