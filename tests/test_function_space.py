@@ -132,3 +132,21 @@ def test_lattice_numbering_is_a_permutation_with_contiguous_rows(p):
     Vb = w.FunctionSpace(mesh, p, bad, w.IndexMap(2 * n ** 3), (0, 0, 0), structured=False)
     nb = w.lattice_numbering(Vb)
     assert sorted(nb.tolist()) == list(range(2 * n ** 3))
+
+
+def test_cxx_mesh_space_and_renumbering(tmp_path):
+    """include/wavehip_mesh.hpp on the host only: function space of a scrambled box (wf_fs_build) and
+    wavehip::renumber_lattice (wf_lattice_numbering) through the C++ wrappers."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import wave_fenics_amd as w
+    w.lib()
+    exe = str(tmp_path / "renumber_smoke")
+    libdir = os.path.join(root, "wave_fenics_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "tests", "cxx", "renumber_smoke.cpp"), "-o", exe, "-L", libdir, "-lwavehip",
+                           f"-Wl,-rpath,{libdir}"])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, (out.returncode, out.stderr)
+    assert out.stdout.split() == [str(13 * 10 * 16), "ok"]
